@@ -1,0 +1,421 @@
+// Device-resident FFTree chain T_1 < T_2 < ... < T_N and the iterative, level-by-level drivers of
+// EXTEND / ENTER / EXIT (the reference's recursive extend_impl / enter_impl / exit_impl / redc_impl,
+// /root/reference/src/fftree.rs:72-120, 143-161, 200-224, 232-259, re-expressed as batched sweeps,
+// SURVEY.md Appendix A) plus the on-GPU table precompute (from_tree, src/fftree.rs:318-463).
+//
+// HBM layout ("Moiety precompute layout"): per tree T_m (m = 2e leaves), per moiety
+// parity s in {0,1}, structure-of-arrays tables holding only the half that parity uses:
+//   p0[s], p1[s], np0[s], dinv[s]   e-1 entries, stage k at offset e - 2*h_k   (h_k = e >> (k+1))
+//   w[s], winv[s]                   e entries   (normalisation weights of the parity's leaves)
+//   xe, w1x                         e entries   ENTER combine
+//   A1, B1, NB2, C1, D1, xie        e entries   EXIT pointwise steps with every inverse pre-fused
+// All tables are PLAIN residues; user data stays in the crate's Montgomery form (field_secp256k1.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <mutex>
+#include <cstdio>
+#include "kernels.h"
+#include "host_curve.h"
+
+namespace ecfft {
+
+#define ECFFT_HIP_TRY(x)                                                                   \
+    do { hipError_t e_ = (x); if (e_ != hipSuccess) {                                      \
+             fprintf(stderr, "ecfft: HIP error '%s' at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+             return false; } } while (0)
+
+static inline unsigned ilog2(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
+static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+template <class Fn>
+static inline void foreach_n(hipStream_t s, size_t n, Fn fn) {
+    if (n) hipLaunchKernelGGL(k_foreach<Fn>, dim3(nblocks(n)), dim3(kBlock), 0, s, fn, n);
+}
+
+template <class F>
+class DeviceChain {
+public:
+    using E = typename F::elem;
+    struct Tree {
+        size_t m = 0, e = 0; unsigned log_m = 0;
+        E *p0[2] = {}, *p1[2] = {}, *np0[2] = {}, *dinv[2] = {};
+        E *w[2] = {}, *winv[2] = {};
+        E *xe = nullptr, *w1x = nullptr, *A1 = nullptr, *B1 = nullptr, *NB2 = nullptr, *C1 = nullptr, *D1 = nullptr, *xie = nullptr;
+        // the reference's own tables (src/fftree.rs:30-37), plain form, kept for construction/export
+        E *xnn = nullptr, *xnn_inv = nullptr, *z0_s1 = nullptr, *z1_s0 = nullptr, *z0_inv_s1 = nullptr,
+          *z1_inv_s0 = nullptr, *z0z0 = nullptr, *z1z1 = nullptr;
+    };
+
+    ~DeviceChain() { release(); }
+
+    size_t size() const { return N_; }
+    unsigned log_size() const { return L_; }
+    const Tree& tree(unsigned log_m) const { return trees_[log_m]; }
+    const HostTree<F>& host() const { return host_; }
+    const E* f_device() const { return f_; }
+    std::mutex& lock() { return mu_; }
+
+    // ------------------------------------------------------------------------------------------
+    // construction
+    // ------------------------------------------------------------------------------------------
+    bool build(HostTree<F>&& ht, int device) {
+        host_ = std::move(ht);
+        N_ = host_.n; L_ = ilog2(N_); device_ = device;
+        ECFFT_HIP_TRY(hipSetDevice(device_));
+        hipStream_t s = nullptr;
+        // arena: 16 elements per leaf per tree, chain sums to < 32 N; + f (2N) + den coefficients
+        size_t total = 2 * N_ + 64;
+        for (unsigned l = 0; l <= L_; ++l) total += 16 * ((size_t)1 << l) + 512;
+        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+        arena_cap_ = total; arena_used_ = 0;
+        f_ = take(2 * N_);
+        ECFFT_HIP_TRY(hipMemcpyAsync(f_, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
+        // denominators of the maps: v_k(x) = den0 + den1 x (degree 1 for both curve families)
+        std::vector<E> den(2 * (L_ ? L_ : 1));
+        for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
+        den_ = take(2 * (L_ ? L_ : 1));
+        ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
+        // transform scratch: 4 N
+        ECFFT_HIP_TRY(hipMalloc(&scratch_, 4 * N_ * sizeof(E)));
+        trees_.resize(L_ + 1);
+        for (unsigned l = 0; l <= L_; ++l) {
+            if (!build_tree(l, s)) return false;
+        }
+        ECFFT_HIP_TRY(hipStreamSynchronize(s));
+        for (void* p : temps_) (void)hipFree(p);
+        temps_.clear();
+        return true;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // EXTEND core: all 2*log(e) normalised stages, in place, on `total` elements = count vectors
+    // of length e = m/2 laid end to end.  src = parity of the moiety the data lives on.
+    // ------------------------------------------------------------------------------------------
+    void extend_core(unsigned log_m, E* buf, size_t total, int src, hipStream_t s) const {
+        const Tree& T = trees_[log_m];
+        size_t e = T.e; unsigned le = ilog2(e);
+        int tgt = 1 - src;
+        size_t npairs = total / 2;
+        for (unsigned k = 0; k < le; ++k) {
+            size_t h = e >> (k + 1), off = e - 2 * h;
+            hipLaunchKernelGGL(k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s, buf, T.np0[src] + off,
+                               T.dinv[src] + off, ilog2(h), npairs);
+        }
+        for (unsigned k = le; k-- > 0;) {
+            size_t h = e >> (k + 1), off = e - 2 * h;
+            hipLaunchKernelGGL(k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s, buf, T.p0[tgt] + off,
+                               T.p1[tgt] + off, ilog2(h), npairs);
+        }
+    }
+
+    // FFTree::extend (src/fftree.rs:123-126) on `count` vectors of length e: uses T_{2e}; `target`
+    // names the TARGET moiety.  in/out device pointers (may alias).
+    void extend(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) const {
+        unsigned log_m = ilog2(e) + 1;
+        const Tree& T = trees_[log_m];
+        size_t total = e * count; int src = 1 - target;
+        hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, out, in, T.winv[src], e - 1, total);
+        extend_core(log_m, out, total, src, s);
+        hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, out, (const E*)out, T.w[target], e - 1, total);
+    }
+
+    // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.
+    // in/out: device pointers, n elements, may alias.  Uses ctx scratch (caller holds lock()).
+    void enter(const E* in, E* out, size_t n, hipStream_t s) const {
+        if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, sizeof(E), hipMemcpyDeviceToDevice, s); return; }
+        E* bufA = scratch_; E* bufB = scratch_ + N_; E* work = scratch_ + 2 * N_;
+        const E* src = in;
+        unsigned ln = ilog2(n);
+        for (unsigned l = 1; l <= ln; ++l) {
+            const Tree& T = trees_[l];
+            size_t e = T.e;
+            E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
+            hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(n)), dim3(kBlock), 0, s, work, src, T.winv[0], e - 1, n);
+            extend_core(l, work, n, 0, s);
+            hipLaunchKernelGGL(k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s, dst, src, (const E*)work, T.xe,
+                               T.w[1], T.w1x, ilog2(e), n / 2);
+            src = dst;
+        }
+        if (src != out) (void)hipMemcpyAsync(out, src, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+    }
+
+    // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
+    void exit(const E* in, E* out, size_t n, hipStream_t s) const {
+        if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, sizeof(E), hipMemcpyDeviceToDevice, s); return; }
+        E* bufA = scratch_; E* bufB = scratch_ + N_; E* G = scratch_ + 2 * N_; E* H = scratch_ + 3 * N_;
+        const E* cur = in;
+        unsigned ln = ilog2(n);
+        size_t nh = n / 2;
+        for (unsigned l = ln; l >= 1; --l) {
+            const Tree& T = trees_[l];
+            unsigned le = ilog2(T.e);
+            E* dst = (l == 1 && out != in) ? out : (cur == bufA ? bufB : bufA);
+            dim3 g(nblocks(nh)), b(kBlock);
+            hipLaunchKernelGGL(k_exit_pre1<F>, g, b, 0, s, G, cur, T.A1, le, nh);
+            extend_core(l, G, nh, 0, s);
+            hipLaunchKernelGGL(k_exit_mid1<F>, g, b, 0, s, G, H, cur, T.B1, T.NB2, le, nh);
+            extend_core(l, G, nh, 1, s);
+            hipLaunchKernelGGL(k_scale_by_table<F>, g, b, 0, s, G, (const E*)G, T.C1, T.e - 1, nh);
+            extend_core(l, G, nh, 0, s);
+            hipLaunchKernelGGL(k_exit_mid2<F>, g, b, 0, s, G, (const E*)H, T.D1, T.NB2, le, nh);
+            extend_core(l, G, nh, 1, s);
+            hipLaunchKernelGGL(k_exit_split<F>, g, b, 0, s, dst, cur, (const E*)G, T.w[0], T.xie, le, nh);
+            cur = dst;
+        }
+        if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+    }
+
+    E* scratch() const { return scratch_; }
+
+private:
+    // ---- memory ----
+    E* take(size_t n) {
+        size_t a = (n + 7) & ~(size_t)7;
+        if (arena_used_ + a > arena_cap_) { fprintf(stderr, "ecfft: arena overflow\n"); abort(); }
+        E* p = arena_ + arena_used_; arena_used_ += a; return p;
+    }
+    E* temp(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, (n ? n : 1) * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: temp alloc failed\n"); abort(); }
+        temps_.push_back(p); return (E*)p;
+    }
+    void release() {
+        for (void* p : temps_) (void)hipFree(p);
+        temps_.clear();
+        if (arena_) (void)hipFree(arena_);
+        if (scratch_) (void)hipFree(scratch_);
+        arena_ = nullptr; scratch_ = nullptr;
+    }
+
+    // ---- construction-time device primitives (plain data) ----
+    // out[i] = 1/in[i]; chunks of 8 share one Fermat inversion (Montgomery's trick)
+    void batch_inv(const E* in, E* out, size_t n, hipStream_t s) {
+        constexpr size_t CH = 8;
+        size_t nth = (n + CH - 1) / CH;
+        foreach_n(s, nth, [=] __device__(size_t t) {
+            size_t b = t * CH, cnt = (b + CH <= n) ? CH : n - b;
+            E pre[CH], v[CH];
+            E acc = F::one();
+            for (size_t i = 0; i < cnt; ++i) { v[i] = in[b + i]; pre[i] = acc; acc = F::mul(acc, v[i]); }
+            acc = F::inv(acc);
+            for (size_t i = cnt; i-- > 0;) { out[b + i] = F::mul(acc, pre[i]); acc = F::mul(acc, v[i]); }
+        });
+    }
+    void ew_mul(E* out, const E* a, const E* b, size_t n, hipStream_t s) {
+        foreach_n(s, n, [=] __device__(size_t i) { out[i] = F::mul(a[i], b[i]); });
+    }
+    // FFTree::extend for construction (whole-vector form with pre/post scaling)
+    void b_extend(unsigned log_m, const E* in, E* out, size_t count, int target, hipStream_t s) {
+        extend(in, out, trees_[log_m].e, count, target, s);
+    }
+    // mextend (src/fftree.rs:128-141)
+    void b_mextend(unsigned log_m, const E* in, E* out, size_t count, int target, hipStream_t s) {
+        const Tree& T = trees_[log_m];
+        b_extend(log_m, in, out, count, target, s);
+        const E* z = target == 1 ? T.z0_s1 : T.z1_s0;
+        size_t mask = T.e - 1;
+        foreach_n(s, T.e * count, [=] __device__(size_t i) { out[i] = F::add(out[i], z[i & mask]); });
+    }
+    // redc_impl with moiety S0 (src/fftree.rs:232-259); a0inv/a1: e entries; evals/out: m entries
+    void b_redc_s0(unsigned log_m, const E* evals, const E* a0inv, const E* a1, E* out, hipStream_t s) {
+        const Tree& T = trees_[log_m];
+        size_t e = T.e;
+        E* t0 = temp(e); E* h1 = temp(e);
+        foreach_n(s, e, [=] __device__(size_t i) { t0[i] = F::mul(evals[2 * i], a0inv[i]); });
+        b_extend(log_m, t0, t0, 1, 1, s);                                   // g1 on S1
+        const E* zinv = T.z0_inv_s1;
+        foreach_n(s, e, [=] __device__(size_t i) {
+            h1[i] = F::mul(F::sub(evals[2 * i + 1], F::mul(t0[i], a1[i])), zinv[i]);
+        });
+        b_extend(log_m, h1, t0, 1, 0, s);                                   // h0 on S0
+        foreach_n(s, e, [=] __device__(size_t i) { out[2 * i] = t0[i]; out[2 * i + 1] = h1[i]; });
+    }
+    // modular_reduce_impl (src/fftree.rs:277-281)
+    void b_modular_reduce(unsigned log_m, const E* evals, const E* a0inv, const E* a1, const E* c, E* out, hipStream_t s) {
+        size_t m = trees_[log_m].m;
+        E* h = temp(m);
+        b_redc_s0(log_m, evals, a0inv, a1, h, s);
+        ew_mul(h, h, c, m, s);
+        b_redc_s0(log_m, h, a0inv, a1, out, s);
+    }
+    // vanish_impl (src/fftree.rs:291-308), bottom-up: dom has e = m/2 entries, out m entries
+    void b_vanish(unsigned log_m, const E* dom, E* out, hipStream_t s) {
+        const Tree& T = trees_[log_m];
+        size_t e = T.e, m = T.m;
+        E* Q = temp(m); E* Q2 = temp(m); E* q0 = temp(e); E* q1 = temp(e);
+        const E* f = f_; size_t N = N_;
+        foreach_n(s, e, [=] __device__(size_t i) {        // T_2 leaves are the top tree's leaves 0 and N/2
+            Q[2 * i] = F::sub(dom[i], f[N]); Q[2 * i + 1] = F::sub(dom[i], f[N + N / 2]);
+        });
+        unsigned le = ilog2(e);
+        for (unsigned r = 1; r <= le; ++r) {
+            size_t bs = (size_t)1 << r;                     // size of the blocks being merged
+            foreach_n(s, e, [=] __device__(size_t g) {
+                size_t b = g >> r, i = g & (bs - 1);
+                q0[g] = F::mul(Q[(2 * b) * bs + i], Q[(2 * b + 1) * bs + i]);
+            });
+            b_mextend(r + 1, q0, q1, e >> r, 1, s);
+            E* dstQ = (r == le) ? out : Q2;
+            foreach_n(s, e, [=] __device__(size_t g) { dstQ[2 * g] = q0[g]; dstQ[2 * g + 1] = q1[g]; });
+            E* t = Q; Q = Q2; Q2 = t;
+        }
+        if (le == 0) (void)hipMemcpyAsync(out, Q, m * sizeof(E), hipMemcpyDeviceToDevice, s);
+    }
+
+    bool build_tree(unsigned l, hipStream_t s) {
+        Tree& T = trees_[l];
+        size_t m = (size_t)1 << l, e = m / 2;
+        T.m = m; T.e = e; T.log_m = l;
+        const E* f = f_; size_t N = N_; size_t stride = N_ / m;
+        T.xnn = take(m); T.xnn_inv = take(m);
+        {
+            E* xnn = T.xnn; uint64_t ex = m / 2;
+            foreach_n(s, m, [=] __device__(size_t j) { xnn[j] = F::pow_u64(f[N + j * stride], ex); });
+            batch_inv(T.xnn, T.xnn_inv, m, s);
+        }
+        if (l == 0) return true;
+        unsigned le = ilog2(e);
+        size_t es = e > 1 ? e : 1;
+        for (int sg = 0; sg < 2; ++sg) {
+            T.p0[sg] = take(es); T.p1[sg] = take(es); T.np0[sg] = take(es); T.dinv[sg] = take(es);
+            T.w[sg] = take(es); T.winv[sg] = take(es);
+            E *p0 = T.p0[sg], *p1 = T.p1[sg], *np0 = T.np0[sg], *dinv = T.dinv[sg];
+            if (e > 1) {
+                // entry g of the concatenated stage tables: stage k = number of leading ones ... computed by scan
+                foreach_n(s, e - 1, [=] __device__(size_t g) {
+                    // stage k occupies [e - 2h, e - h), h = e >> (k+1)
+                    size_t rem = e - g;                       // in (h, 2h]
+                    unsigned k = 0; size_t h = e >> 1;
+                    while (rem <= h) { h >>= 1; ++k; }
+                    size_t i = g - (e - 2 * h);
+                    size_t lay = N >> k;                      // offset (= size) of layer k in the top tree
+                    E a = f[lay + (2 * i + sg) * stride];
+                    E b = f[lay + (2 * i + sg + 2 * h) * stride];
+                    p0[g] = a; p1[g] = b; np0[g] = F::neg(a); dinv[g] = F::sub(b, a);
+                });
+                batch_inv(dinv, dinv, e - 1, s);
+            }
+            // normalisation weights W(s) of the leaves of parity sg (DESIGN.md "Normalised butterflies")
+            E* w = T.w[sg]; const E* den = den_;
+            foreach_n(s, e, [=] __device__(size_t i) {
+                size_t j = 2 * i + sg;
+                E U = F::one(), C = F::one();
+                for (unsigned b = 0; b + 1 < le; ++b) {
+                    size_t lsz = m >> b;                      // |L_b| of T_m
+                    E sb = f[(N >> b) + (j & (lsz - 1)) * stride];
+                    E V = F::mul_add(den[2 * b + 1], sb, den[2 * b]);
+                    C = F::mul(C, V);
+                    U = F::mul(F::sqr(U), C);
+                }
+                w[i] = U;
+            });
+            batch_inv(T.w[sg], T.winv[sg], e, s);
+        }
+        T.z0_s1 = take(es); T.z1_s0 = take(es); T.z0_inv_s1 = take(es); T.z1_inv_s0 = take(es);
+        T.z0z0 = take(m); T.z1z1 = take(m);
+        if (l == 1) {                                          // base cases src/fftree.rs:399-403, 454-458
+            E *z0 = T.z0_s1, *z1 = T.z1_s0, *zz0 = T.z0z0, *zz1 = T.z1z1;
+            foreach_n(s, 1, [=] __device__(size_t) {
+                E s0 = f[N], s1 = f[N + stride];
+                z0[0] = F::sub(s1, s0); z1[0] = F::sub(s0, s1);
+                zz0[0] = zz0[1] = F::sqr(s0); zz1[0] = zz1[1] = F::sqr(s1);
+            });
+        } else {
+            const Tree& S = trees_[l - 1];
+            // z0_s1 (src/fftree.rs:386-393)
+            E* a = temp(e); E* b = temp(e);
+            {
+                const E *sz0 = S.z0_s1, *sz1 = S.z1_s0;
+                foreach_n(s, e / 2, [=] __device__(size_t i) {
+                    a[2 * i] = F::zero(); a[2 * i + 1] = sz0[i];
+                    b[2 * i] = sz1[i]; b[2 * i + 1] = F::zero();
+                });
+            }
+            b_extend(l, a, a, 1, 1, s);
+            b_extend(l, b, b, 1, 1, s);
+            ew_mul(T.z0_s1, a, b, e, s);
+            // z1_s0 = vanish(S1)[even]  (src/fftree.rs:396-397)
+            E* s1 = temp(e); E* van = temp(m);
+            foreach_n(s, e, [=] __device__(size_t i) { s1[i] = f[N + (2 * i + 1) * stride]; });
+            b_vanish(l, s1, van, s);
+            { E* z1 = T.z1_s0; foreach_n(s, e, [=] __device__(size_t i) { z1[i] = van[2 * i]; }); }
+        }
+        batch_inv(T.z0_s1, T.z0_inv_s1, e, s);
+        batch_inv(T.z1_s0, T.z1_inv_s0, e, s);
+        if (l >= 2) {
+            const Tree& S = trees_[l - 1];
+            // a0inv / a1 views of xnn_s for REDC on this tree and on the subtree
+            E* xa0i = temp(e); E* xa1 = temp(e);
+            { const E *xi = T.xnn_inv, *x = T.xnn; foreach_n(s, e, [=] __device__(size_t i) { xa0i[i] = xi[2 * i]; xa1[i] = x[2 * i + 1]; }); }
+            E* sxa0i = temp(e / 2 ? e / 2 : 1); E* sxa1 = temp(e / 2 ? e / 2 : 1);
+            { const E *xi = S.xnn_inv, *x = S.xnn; foreach_n(s, e / 2, [=] __device__(size_t i) { sxa0i[i] = xi[2 * i]; sxa1[i] = x[2 * i + 1]; }); }
+            // X^(m/4) tables on the leaves of T_m (src/fftree.rs:328-330)
+            E* xq = temp(m); E* xqi = temp(m);
+            { uint64_t ex = m / 4; foreach_n(s, m, [=] __device__(size_t j) { xq[j] = F::pow_u64(f[N + j * stride], ex); }); }
+            batch_inv(xq, xqi, m, s);
+            E* xqa0i = temp(e); E* xqa1 = temp(e);
+            foreach_n(s, e, [=] __device__(size_t i) { xqa0i[i] = xqi[2 * i]; xqa1[i] = xq[2 * i + 1]; });
+            // z0z0_rem_xnn_s (src/fftree.rs:418-446)
+            E* sq = temp(e); E* zz0 = temp(e); E* zz1 = temp(e); E* zz = temp(m); E* tmp = temp(m); E* dr = temp(m);
+            ew_mul(sq, S.z0z0, S.z1z1, e, s);                                       // :421-423
+            b_modular_reduce(l - 1, sq, sxa0i, sxa1, S.z0z0, zz0, s);               // :424-425
+            b_extend(l, zz0, zz1, 1, 1, s);                                         // :426
+            foreach_n(s, e, [=] __device__(size_t i) { zz[2 * i] = zz0[i]; zz[2 * i + 1] = zz1[i]; });
+            {
+                const E *z0s1 = T.z0_s1, *xnn = T.xnn;
+                foreach_n(s, m, [=] __device__(size_t i) {                           // :430-438
+                    E z0 = (i & 1) ? z0s1[i / 2] : F::zero();
+                    E y = F::sub(z0, xnn[i]);
+                    tmp[i] = F::mul(F::sub(F::sqr(y), zz[i]), xqi[i]);
+                });
+            }
+            b_modular_reduce(l, tmp, xqa0i, xqa1, zz, dr, s);                        // :439-440
+            { E* o = T.z0z0; foreach_n(s, m, [=] __device__(size_t i) { o[i] = F::mul_add(xq[i], dr[i], zz[i]); }); } // :441-446
+            // z1z1_rem_xnn_s (src/fftree.rs:449-452)
+            {
+                const E *z1s0 = T.z1_s0, *xnn = T.xnn;
+                foreach_n(s, m, [=] __device__(size_t i) {
+                    E z1 = (i & 1) ? F::zero() : z1s0[i / 2];
+                    tmp[i] = F::sqr(F::sub(z1, xnn[i]));
+                });
+            }
+            b_modular_reduce(l, tmp, xa0i, xa1, T.z0z0, T.z1z1, s);
+        }
+        // fused pointwise tables of the hot path
+        T.xe = take(es); T.w1x = take(es); T.A1 = take(es); T.B1 = take(es); T.NB2 = take(es);
+        T.C1 = take(es); T.D1 = take(es); T.xie = take(es);
+        {
+            E *xe = T.xe, *w1x = T.w1x, *A1 = T.A1, *B1 = T.B1, *NB2 = T.NB2, *C1 = T.C1, *D1 = T.D1, *xie = T.xie;
+            const E *xnn = T.xnn, *xi = T.xnn_inv, *w1 = T.w[1], *wi0 = T.winv[0], *wi1 = T.winv[1], *zi = T.z0_inv_s1, *c = T.z0z0;
+            foreach_n(s, e, [=] __device__(size_t i) {
+                E xo = xnn[2 * i + 1], xiev = xi[2 * i], z = zi[i];
+                xe[i] = xnn[2 * i];
+                w1x[i] = F::mul(w1[i], xo);
+                xie[i] = xiev;
+                A1[i] = F::mul(xiev, wi0[i]);
+                B1[i] = F::mul(z, wi1[i]);
+                NB2[i] = F::neg(F::mul(xo, z));
+                C1[i] = F::mul(c[2 * i], xiev);
+                D1[i] = F::mul(c[2 * i + 1], z);
+            });
+        }
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) { fprintf(stderr, "ecfft: kernel launch failed: %s\n", hipGetErrorString(err)); return false; }
+        // temporaries are only needed until the stream drains; free them per tree to bound memory
+        if (hipStreamSynchronize(s) != hipSuccess) return false;
+        for (void* p : temps_) (void)hipFree(p);
+        temps_.clear();
+        return true;
+    }
+
+    HostTree<F> host_;
+    size_t N_ = 0; unsigned L_ = 0; int device_ = 0;
+    E* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
+    E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr;
+    std::vector<Tree> trees_;
+    std::vector<void*> temps_;
+    std::mutex mu_;
+};
+
+}  // namespace ecfft

@@ -1,0 +1,285 @@
+// C-ABI of the MI355X ECFFT hot path — implements include/ecfft_hip.h.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <memory>
+#include <new>
+#include "device_tree.h"
+#include "../../include/ecfft_hip.h"
+
+using namespace ecfft;
+
+struct ecfft_ctx {
+    int field;
+    int device;
+    std::unique_ptr<DeviceChain<Secp256k1>> secp;
+    std::unique_ptr<DeviceChain<M31>> m31;
+    void* stage = nullptr;       // device staging for host-pointer calls (in + out), lazily sized
+    size_t stage_bytes = 0;
+    ~ecfft_ctx() { if (stage) (void)hipFree(stage); }
+};
+
+namespace {
+
+inline bool is_pow2(size_t n) { return n && (n & (n - 1)) == 0; }
+
+bool have_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device < 0 || device >= cnt) {
+        fprintf(stderr, "ecfft: no usable HIP device %d (count=%d) — this library has no CPU fallback\n", device, cnt);
+        return false;
+    }
+    return true;
+}
+
+template <class F>
+int finish_build(HostTree<F>&& ht, int device, std::unique_ptr<DeviceChain<F>>& slot) {
+    slot.reset(new (std::nothrow) DeviceChain<F>());
+    if (!slot) return ECFFT_ERR_HIP;
+    return slot->build(std::move(ht), device) ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+
+// plain <-> crate representation on host buffers
+void secp_from_mont_host(Fe256* v, size_t n) {   // x*2^256 -> x : multiply by 2^-256 = (2^32+977)^-1
+    Fe256 r = Secp256k1::zero(); r.l[0] = 977; r.l[1] = 1;
+    Fe256 rinv = Secp256k1::inv(r);
+    for (size_t i = 0; i < n; ++i) v[i] = Secp256k1::mul(v[i], rinv);
+}
+void secp_to_mont_host(Fe256* v, size_t n) { for (size_t i = 0; i < n; ++i) v[i] = Secp256k1::to_mont(v[i]); }
+
+bool ensure_stage(ecfft_ctx* c, size_t bytes) {
+    if (c->stage_bytes >= bytes) return true;
+    if (c->stage) (void)hipFree(c->stage);
+    c->stage = nullptr; c->stage_bytes = 0;
+    if (hipMalloc(&c->stage, bytes) != hipSuccess) return false;
+    c->stage_bytes = bytes;
+    return true;
+}
+
+enum Op { OP_ENTER, OP_EXIT, OP_EXTEND };
+
+template <class F>
+int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, size_t len, size_t count, int moiety,
+           int mem, void* stream) {
+    using E = typename F::elem;
+    if (!in || !out) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(len)) return ECFFT_ERR_NOT_POW2;
+    if (count == 0) return ECFFT_ERR_BAD_ARG;
+    size_t need_tree = (op == OP_EXTEND) ? len * 2 : len;
+    if (need_tree > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;          // "FFTree is too small"
+    if (op == OP_EXTEND && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
+    if (op == OP_EXTEND && len * count > 2 * ch.size() && mem == ECFFT_MEM_HOST) { /* staged below; any count allowed */ }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    std::lock_guard<std::mutex> guard(ch.lock());
+    size_t total = len * count, bytes = total * sizeof(E);
+    const E* din = (const E*)in; E* dout = (E*)out;
+    if (mem == ECFFT_MEM_HOST) {
+        if (!ensure_stage(c, 2 * bytes)) return ECFFT_ERR_HIP;
+        din = (const E*)c->stage; dout = (E*)((char*)c->stage + bytes);
+        if (hipMemcpyAsync((void*)din, in, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP;
+    } else if (mem != ECFFT_MEM_DEVICE) {
+        return ECFFT_ERR_BAD_ARG;
+    }
+    switch (op) {
+        case OP_ENTER: ch.enter(din, dout, len, s); break;
+        case OP_EXIT: ch.exit(din, dout, len, s); break;
+        case OP_EXTEND: ch.extend(din, dout, len, count, moiety, s); break;
+    }
+    if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
+    if (mem == ECFFT_MEM_HOST) {
+        if (hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
+        if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
+    }
+    return ECFFT_OK;
+}
+
+template <class F>
+int table_of(const DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap, size_t* count) {
+    using E = typename F::elem;
+    if (!is_pow2(m)) return ECFFT_ERR_NOT_POW2;
+    if (m > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
+    unsigned l = ilog2(m);
+    const typename DeviceChain<F>::Tree& T = ch.tree(l);
+    const E* src = nullptr; size_t cnt = 0;
+    switch (which) {
+        case ECFFT_TBL_XNN_S: src = T.xnn; cnt = m; break;
+        case ECFFT_TBL_XNN_S_INV: src = T.xnn_inv; cnt = m; break;
+        case ECFFT_TBL_Z0_S1: src = T.z0_s1; cnt = m / 2; break;
+        case ECFFT_TBL_Z1_S0: src = T.z1_s0; cnt = m / 2; break;
+        case ECFFT_TBL_Z0_INV_S1: src = T.z0_inv_s1; cnt = m / 2; break;
+        case ECFFT_TBL_Z1_INV_S0: src = T.z1_inv_s0; cnt = m / 2; break;
+        case ECFFT_TBL_Z0Z0_REM_XNN_S: src = T.z0z0; cnt = m; break;
+        case ECFFT_TBL_Z1Z1_REM_XNN_S: src = T.z1z1; cnt = m; break;
+        case ECFFT_TBL_F: cnt = 2 * m; break;
+        default: return ECFFT_ERR_BAD_ARG;
+    }
+    if (count) *count = cnt;
+    if (!host_out) return ECFFT_OK;
+    if (cap < cnt) return ECFFT_ERR_BAD_ARG;
+    E* o = (E*)host_out;
+    if (which == ECFFT_TBL_F) {
+        // f of T_m: every (N/m)-th element of each layer of the top tree (src/fftree.rs:471-478)
+        const std::vector<E>& f = ch.host().f; size_t N = ch.size(), stride = N / m;
+        o[0] = F::zero();
+        for (size_t sz = m, top = N; sz >= 1; sz >>= 1, top >>= 1) {
+            for (size_t j = 0; j < sz; ++j) o[sz + j] = f[top + j * stride];
+            if (sz == 1) break;
+        }
+    } else if (cnt) {
+        if (!src) return ECFFT_ERR_BAD_ARG;
+        if (hipMemcpy(o, src, cnt * sizeof(E), hipMemcpyDeviceToHost) != hipSuccess) return ECFFT_ERR_HIP;
+    }
+    if constexpr (std::is_same<F, Secp256k1>::value) secp_to_mont_host(o, cnt);
+    return ECFFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
+
+int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!is_pow2(n)) return ECFFT_ERR_NOT_POW2;                           // assert!(n.is_power_of_two())
+    if (field != ECFFT_FIELD_SECP256K1 && field != ECFFT_FIELD_M31) return ECFFT_ERR_BAD_ARG;
+    unsigned log_n = ilog2(n);
+    // size limits first (they do not need a device): src/lib.rs:62-64, src/ec.rs:510-515
+    if (field == ECFFT_FIELD_SECP256K1 && log_n >= 36) return ECFFT_ERR_TREE_TOO_LARGE;
+    if (field == ECFFT_FIELD_M31 && log_n > 28) return ECFFT_ERR_TREE_TOO_LARGE;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    std::unique_ptr<ecfft_ctx> c(new (std::nothrow) ecfft_ctx());
+    if (!c) return ECFFT_ERR_HIP;
+    c->field = field; c->device = device;
+    int rc;
+    if (field == ECFFT_FIELD_SECP256K1) {
+        HostTree<Secp256k1> ht;
+        int r = build_host_tree<Secp256k1>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        rc = finish_build(std::move(ht), device, c->secp);
+    } else {
+        HostTree<M31> ht;
+        int r = build_host_tree<M31>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        rc = finish_build(std::move(ht), device, c->m31);
+    }
+    if (rc != ECFFT_OK) return rc;
+    *out = c.release();
+    return ECFFT_OK;
+}
+
+int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_num3, const void* map_den3, int device,
+                     ecfft_ctx** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!leaves || (n > 1 && (!map_num3 || !map_den3))) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(n)) return ECFFT_ERR_NOT_POW2;
+    if (field != ECFFT_FIELD_SECP256K1 && field != ECFFT_FIELD_M31) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    unsigned log_n = ilog2(n);
+    std::unique_ptr<ecfft_ctx> c(new (std::nothrow) ecfft_ctx());
+    if (!c) return ECFFT_ERR_HIP;
+    c->field = field; c->device = device;
+    int rc;
+    if (field == ECFFT_FIELD_SECP256K1) {
+        HostTree<Secp256k1> ht; ht.n = n; ht.f.assign(2 * n, Secp256k1::zero()); ht.maps.resize(log_n);
+        memcpy(ht.f.data() + n, leaves, n * 32);
+        secp_from_mont_host(ht.f.data() + n, n);
+        for (unsigned k = 0; k < log_n; ++k) {
+            memcpy(ht.maps[k].num, (const char*)map_num3 + 96 * k, 96); memcpy(ht.maps[k].den, (const char*)map_den3 + 96 * k, 96);
+            secp_from_mont_host(ht.maps[k].num, 3); secp_from_mont_host(ht.maps[k].den, 3);
+            if (!Secp256k1::is_zero(ht.maps[k].den[2])) return ECFFT_ERR_BAD_ARG;   // x-map denominators have degree 1
+        }
+        if (!fill_layers<Secp256k1>(ht)) return ECFFT_ERR_BAD_ARG;
+        rc = finish_build(std::move(ht), device, c->secp);
+    } else {
+        HostTree<M31> ht; ht.n = n; ht.f.assign(2 * n, 0); ht.maps.resize(log_n);
+        memcpy(ht.f.data() + n, leaves, n * 4);
+        for (unsigned k = 0; k < log_n; ++k) {
+            memcpy(ht.maps[k].num, (const char*)map_num3 + 12 * k, 12); memcpy(ht.maps[k].den, (const char*)map_den3 + 12 * k, 12);
+            if (ht.maps[k].den[2] != 0) return ECFFT_ERR_BAD_ARG;
+        }
+        if (!fill_layers<M31>(ht)) return ECFFT_ERR_BAD_ARG;
+        rc = finish_build(std::move(ht), device, c->m31);
+    }
+    if (rc != ECFFT_OK) return rc;
+    *out = c.release();
+    return ECFFT_OK;
+}
+
+int ecfft_build_points(int field, size_t n, void* f_out, void* map_num3_out, void* map_den3_out) {
+    if (!f_out) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(n)) return ECFFT_ERR_NOT_POW2;
+    unsigned log_n = ilog2(n);
+    if (field == ECFFT_FIELD_SECP256K1) {
+        HostTree<Secp256k1> ht;
+        int r = build_host_tree<Secp256k1>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        secp_to_mont_host(ht.f.data(), 2 * n);
+        memcpy(f_out, ht.f.data(), 2 * n * 32);
+        for (unsigned k = 0; k < log_n; ++k) {
+            secp_to_mont_host(ht.maps[k].num, 3); secp_to_mont_host(ht.maps[k].den, 3);
+            if (map_num3_out) memcpy((char*)map_num3_out + 96 * k, ht.maps[k].num, 96);
+            if (map_den3_out) memcpy((char*)map_den3_out + 96 * k, ht.maps[k].den, 96);
+        }
+        return ECFFT_OK;
+    }
+    if (field == ECFFT_FIELD_M31) {
+        HostTree<M31> ht;
+        int r = build_host_tree<M31>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        memcpy(f_out, ht.f.data(), 2 * n * 4);
+        for (unsigned k = 0; k < log_n; ++k) {
+            if (map_num3_out) memcpy((char*)map_num3_out + 12 * k, ht.maps[k].num, 12);
+            if (map_den3_out) memcpy((char*)map_den3_out + 12 * k, ht.maps[k].den, 12);
+        }
+        return ECFFT_OK;
+    }
+    return ECFFT_ERR_BAD_ARG;
+}
+
+void ecfft_ctx_destroy(ecfft_ctx* ctx) { delete ctx; }
+
+size_t ecfft_tree_size(const ecfft_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->size() : ctx->m31->size();
+}
+int ecfft_field(const ecfft_ctx* ctx) { return ctx ? ctx->field : -1; }
+
+int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream);
+}
+int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream);
+}
+int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXTEND, in, out, e, count, moiety, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXTEND, in, out, e, count, moiety, mem, stream);
+}
+
+int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ECFFT_ERR_HIP;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)
+                                               : table_of(*ctx->m31, m, which, host_out, cap, count);
+}
+
+int ecfft_device_info(int device, char* buf, size_t cap) {
+    if (!buf || !cap) return ECFFT_ERR_BAD_ARG;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { snprintf(buf, cap, "no HIP device"); return ECFFT_ERR_HIP; }
+    snprintf(buf, cap, "%s (%s), %d CUs, %.1f GiB", p.name, p.gcnArchName, p.multiProcessorCount, p.totalGlobalMem / 1073741824.0);
+    return ECFFT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Mersenne-31 field for the MI355X path: p = 2^31 - 1, one u32 per element holding the plain
+// canonical residue — the in-memory form of `ark_ff_optimized::fp31::Fp` (/root/reference/src/lib.rs:196).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ecfft {
+
+struct M31 {
+    using elem = uint32_t;
+    static constexpr int kBytes = 4;
+    static constexpr int kFieldId = 1;
+    static constexpr uint32_t P = 0x7FFFFFFFu;
+
+    __host__ __device__ static inline elem zero() { return 0; }
+    __host__ __device__ static inline elem one() { return 1; }
+    __host__ __device__ static inline elem from_u32(uint32_t v) { return v % P; }
+    __host__ __device__ static inline bool is_zero(elem a) { return a == 0; }
+    __host__ __device__ static inline bool eq(elem a, elem b) { return a == b; }
+    __host__ __device__ static inline elem add(elem a, elem b) { uint32_t s = a + b; return s >= P ? s - P : s; }
+    __host__ __device__ static inline elem sub(elem a, elem b) { return a >= b ? a - b : a + P - b; }
+    __host__ __device__ static inline elem neg(elem a) { return a ? P - a : 0; }
+    __host__ __device__ static inline elem red64(uint64_t t) {  // t < 2^63
+        uint32_t r = (uint32_t)(t & P) + (uint32_t)((t >> 31) & P) + (uint32_t)(t >> 62);
+        r = (r & P) + (r >> 31);
+        return r >= P ? r - P : r;
+    }
+    __host__ __device__ static inline elem mul(elem t, elem x) { return red64((uint64_t)t * x); }
+    __host__ __device__ static inline elem mul_add(elem t, elem x, elem c) { return red64((uint64_t)t * x + c); }
+    __host__ __device__ static inline elem sqr(elem a) { return mul(a, a); }
+    __host__ __device__ static inline elem pow_u64(elem a, uint64_t e) {
+        elem r = 1;
+        for (int i = 63; i >= 0; --i) { r = sqr(r); if ((e >> i) & 1) r = mul(r, a); }
+        return r;
+    }
+    __host__ __device__ static inline elem inv(elem a) { return pow_u64(a, P - 2); }
+    __host__ static inline bool sqrt(elem a, elem* out) {
+        elem r = pow_u64(a, ((uint64_t)P + 1) / 4);
+        if (sqr(r) != a) return false;
+        *out = r; return true;
+    }
+    __host__ __device__ static inline elem to_mont(elem a) { return a; }
+    __host__ static inline int cmp(elem a, elem b) { return a < b ? -1 : (a > b ? 1 : 0); }
+};
+
+}  // namespace ecfft

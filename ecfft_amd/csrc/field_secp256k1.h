@@ -1,0 +1,189 @@
+// secp256k1 base field for the MI355X path: p = 2^256 - 2^32 - 977.
+//
+// Replaces the arithmetic the reference gets from ark-ff (`Fp256<MontBackend<FqConfig, 4>>`,
+// /root/reference/src/lib.rs:31-37; call sites src/utils.rs:341-346, src/fftree.rs:94,115,157-158,
+// 217-219,238,253-255,279).
+//
+// Representation contract.  USER DATA crosses the C-ABI in the crate's in-memory form: four
+// little-endian u64 limbs holding x*2^256 mod p (Montgomery form), fully reduced.  Every multiply on
+// the ENTER/EXIT/EXTEND path is data x precomputed-constant (never data x data), so all TABLES are
+// kept in PLAIN form t and the device computes the plain product (xR)*t mod p = (x t)R: data stays in
+// Montgomery form bit-exactly and no Montgomery reduction is ever executed.  The 512-bit product is
+// reduced with the pseudo-Mersenne fold 2^256 = 2^32 + 977 (mod p).
+//
+// Device code uses 8 x u32 limbs so that every partial product is one v_mad_u64_u32 (measured on
+// gfx950: ~5 cycles per wave-instruction, see tools/ubench/intops.hip); host code (tree construction
+// only) uses 4 x u64 limbs with unsigned __int128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ecfft {
+
+struct alignas(16) Fe256 {
+    uint32_t l[8];
+};
+
+struct Secp256k1 {
+    using elem = Fe256;
+    static constexpr int kBytes = 32;
+    static constexpr int kFieldId = 0;
+    static constexpr uint32_t C977 = 977u;  // p = 2^256 - (2^32 + 977)
+
+    __host__ __device__ static inline elem zero() { elem r; for (int i = 0; i < 8; ++i) r.l[i] = 0; return r; }
+    __host__ __device__ static inline elem from_u32(uint32_t v) { elem r = zero(); r.l[0] = v; return r; }
+    __host__ __device__ static inline elem one() { return from_u32(1); }
+    __host__ __device__ static inline bool is_zero(const elem& a) {
+        uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= a.l[i]; return o == 0;
+    }
+    __host__ __device__ static inline bool eq(const elem& a, const elem& b) {
+        uint32_t o = 0; for (int i = 0; i < 8; ++i) o |= a.l[i] ^ b.l[i]; return o == 0;
+    }
+    __host__ __device__ static inline uint32_t p_limb(int i) { return i == 0 ? 0xFFFFFC2Fu : (i == 1 ? 0xFFFFFFFEu : 0xFFFFFFFFu); }
+
+    // a + b mod p, inputs canonical
+    __host__ __device__ static inline elem add(const elem& a, const elem& b) {
+        uint32_t s[8]; uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c += (uint64_t)a.l[i] + b.l[i]; s[i] = (uint32_t)c; c >>= 32; }
+        return finish(s, (uint32_t)c);
+    }
+    // a - b mod p
+    __host__ __device__ static inline elem sub(const elem& a, const elem& b) {
+        uint32_t d[8]; int64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { int64_t t = (int64_t)a.l[i] - b.l[i] + bw; d[i] = (uint32_t)t; bw = t >> 32; }
+        // if borrow: add p  (= subtract 2^32 + 977 modulo 2^256)
+        uint32_t m = (uint32_t)bw;  // 0 or 0xFFFFFFFF
+        elem r; int64_t c2 = 0;
+        uint32_t k0 = m & C977, k1 = m & 1u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int64_t t = (int64_t)d[i] - (i == 0 ? k0 : (i == 1 ? k1 : 0u)) + c2; r.l[i] = (uint32_t)t; c2 = t >> 32;
+        }
+        return r;
+    }
+    __host__ __device__ static inline elem neg(const elem& a) { return sub(zero(), a); }
+
+    // value = s + carry*2^256 < 2^256 + 2^255 (say); returns it mod p, canonical
+    __host__ __device__ static inline elem finish(const uint32_t s[8], uint32_t carry) {
+        // u = s + (2^32 + 977); if that overflows 2^256 (or carry was set) then value >= p -> take u
+        uint32_t u[8]; uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c += (uint64_t)s[i] + (i == 0 ? C977 : (i == 1 ? 1u : 0u)); u[i] = (uint32_t)c; c >>= 32;
+        }
+        bool ge = (carry | (uint32_t)c) != 0;
+        elem r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.l[i] = ge ? u[i] : s[i];
+        return r;
+    }
+
+    // w[0..15] = t * x + c   (c may be null => 0).  Operand scanning; each step is one v_mad_u64_u32
+    __host__ __device__ static inline void mul_wide(const elem& t, const elem& x, const elem* c, uint32_t w[16]) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host (tree construction only): 4 x u64 limbs
+        typedef unsigned __int128 u128;
+        uint64_t T[4], X[4], W[8];
+        for (int i = 0; i < 4; ++i) {
+            T[i] = (uint64_t)t.l[2 * i] | ((uint64_t)t.l[2 * i + 1] << 32);
+            X[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
+            W[i] = c ? ((uint64_t)c->l[2 * i] | ((uint64_t)c->l[2 * i + 1] << 32)) : 0; W[i + 4] = 0;
+        }
+        for (int i = 0; i < 4; ++i) {
+            uint64_t carry = 0;
+            for (int j = 0; j < 4; ++j) {
+                u128 acc = (u128)T[i] * X[j] + W[i + j] + carry; W[i + j] = (uint64_t)acc; carry = (uint64_t)(acc >> 64);
+            }
+            W[i + 4] = carry;
+        }
+        for (int i = 0; i < 8; ++i) { w[2 * i] = (uint32_t)W[i]; w[2 * i + 1] = (uint32_t)(W[i] >> 32); }
+        return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = c ? c->l[j] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint64_t acc = (uint64_t)t.l[i] * x.l[j] + w[i + j] + carry;
+                w[i + j] = (uint32_t)acc; carry = acc >> 32;
+            }
+            w[i + 8] = (uint32_t)carry;
+        }
+    }
+    // 512-bit w -> canonical residue mod p
+    __host__ __device__ static inline elem reduce_wide(const uint32_t w[16]) {
+        // fold 1: v = lo + hi*977 + (hi << 32)   (10 words)
+        uint32_t v[8]; uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc += (uint64_t)w[8 + j] * C977 + w[j] + (j ? w[8 + j - 1] : 0u);
+            v[j] = (uint32_t)acc; acc >>= 32;
+        }
+        acc += w[15];                       // top = acc < 2^34
+        // fold 2: v += top*977 + (top << 32)
+        uint64_t top = acc;
+        uint64_t a0 = top * C977;           // < 2^44
+        uint64_t c = (uint64_t)v[0] + (uint32_t)a0; v[0] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)v[1] + (a0 >> 32) + (uint32_t)top; v[1] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)v[2] + (top >> 32); v[2] = (uint32_t)c; c >>= 32;
+#pragma unroll
+        for (int j = 3; j < 8; ++j) { c += v[j]; v[j] = (uint32_t)c; c >>= 32; }
+        return finish(v, (uint32_t)c);
+    }
+    // t*x mod p
+    __host__ __device__ static inline elem mul(const elem& t, const elem& x) {
+        uint32_t w[16]; mul_wide(t, x, nullptr, w); return reduce_wide(w);
+    }
+    // t*x + c mod p  (the modular add is free: c seeds the accumulator of the first row)
+    __host__ __device__ static inline elem mul_add(const elem& t, const elem& x, const elem& c) {
+        uint32_t w[16]; mul_wide(t, x, &c, w); return reduce_wide(w);
+    }
+    __host__ __device__ static inline elem sqr(const elem& a) { return mul(a, a); }
+
+    __host__ __device__ static inline elem pow_u64(const elem& a, uint64_t e) {
+        elem r = one();
+        for (int i = 63; i >= 0; --i) { r = sqr(r); if ((e >> i) & 1) r = mul(r, a); }
+        return r;
+    }
+    // a^(p-2); p-2 = 2^256 - 2^32 - 979 = [0xFFFFFC2D, 0xFFFFFFFE, 0xFFFFFFFF x6]
+    __host__ __device__ static inline elem inv(const elem& a) {
+        elem r = one();
+        for (int i = 255; i >= 0; --i) {
+            r = sqr(r);
+            uint32_t wv = (i >= 64) ? 0xFFFFFFFFu : (i >= 32 ? 0xFFFFFFFEu : 0xFFFFFC2Du);
+            if ((wv >> (i & 31)) & 1) r = mul(r, a);
+        }
+        return r;
+    }
+    // a^((p+1)/4); (p+1)/4 = 2^254 - 2^30 - 244 -> words [0xBFFFFF0C, 0xFFFFFFFF x6, 0x3FFFFFFF]
+    __host__ static inline bool sqrt(const elem& a, elem* out) {
+        elem r = one();
+        for (int i = 255; i >= 0; --i) {
+            r = sqr(r);
+            uint32_t wv = (i >= 224) ? 0x3FFFFFFFu : (i >= 32 ? 0xFFFFFFFFu : 0xBFFFFF0Cu);
+            if ((wv >> (i & 31)) & 1) r = mul(r, a);
+        }
+        if (!eq(sqr(r), a)) return false;
+        *out = r; return true;
+    }
+    // plain <-> Montgomery (x -> x * 2^256 mod p):  2^256 mod p = 2^32 + 977
+    __host__ __device__ static inline elem to_mont(const elem& a) {
+        elem r256 = zero(); r256.l[0] = C977; r256.l[1] = 1; return mul(a, r256);
+    }
+    // host only: decimal literal -> plain element
+    __host__ static inline elem from_dec(const char* s) {
+        elem r = zero(); elem ten = from_u32(10);
+        for (; *s; ++s) r = add(mul(r, ten), from_u32((uint32_t)(*s - '0')));
+        return r;
+    }
+    __host__ static inline int cmp(const elem& a, const elem& b) {
+        for (int i = 7; i >= 0; --i) { if (a.l[i] < b.l[i]) return -1; if (a.l[i] > b.l[i]) return 1; }
+        return 0;
+    }
+};
+
+}  // namespace ecfft

@@ -1,0 +1,167 @@
+// HIP kernels of the ECFFT hot path (gfx950).  Field-generic: F = ecfft::Secp256k1 or ecfft::M31.
+//
+// All butterflies are the NORMALISED form derived in DESIGN.md ("Normalised butterflies"): the
+// reference's 2x2 matrices (src/fftree.rs:355-362)
+//      R = [[v0, s0*v0], [v1, s1*v1]],   D = R^-1,   v_j = v(s_j)^(d/2-1)
+// factor as R = diag(v0, v1) * [[1, s0], [1, s1]].  Carrying the diagonal as a per-point weight W
+// (W_k(s) = v_k(s)^(h_k-1) * W_{k+1}(psi_k(s))) turns every stage into
+//      recombine:  (A, B) -> (A + s0*B, A + s1*B)                       2 field muls, was 4
+//      decompose:  (a, b) -> q1 = (b - a)/(s1 - s0), q0 = a - s0*q1      2 field muls, was 4
+// with one multiply by 1/W on the way in and by W on the way out of an EXTEND (both folded into the
+// neighbouring pointwise tables).  Field elements are canonical residues, so the re-association is
+// bit-exact against the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace ecfft {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// streaming butterfly stages (one launch per stage; used for strides that do not fit one
+// workgroup's LDS tile and as the simple reference path for the fused kernels)
+// buf holds `npairs*2` elements = count vectors of length e laid end to end; h = pair distance.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_decompose_stage(typename F::elem* __restrict__ buf,
+                                                             const typename F::elem* __restrict__ np0,
+                                                             const typename F::elem* __restrict__ dinv,
+                                                             uint32_t log_h, size_t npairs) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= npairs) return;
+    size_t h = (size_t)1 << log_h;
+    size_t i = g & (h - 1);
+    size_t idx = ((g >> log_h) << (log_h + 1)) + i;
+    typename F::elem a = buf[idx], b = buf[idx + h];
+    typename F::elem q1 = F::mul(dinv[i], F::sub(b, a));
+    typename F::elem q0 = F::mul_add(np0[i], q1, a);
+    buf[idx] = q0;
+    buf[idx + h] = q1;
+}
+
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __restrict__ buf,
+                                                             const typename F::elem* __restrict__ p0,
+                                                             const typename F::elem* __restrict__ p1,
+                                                             uint32_t log_h, size_t npairs) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= npairs) return;
+    size_t h = (size_t)1 << log_h;
+    size_t i = g & (h - 1);
+    size_t idx = ((g >> log_h) << (log_h + 1)) + i;
+    typename F::elem a = buf[idx], b = buf[idx + h];
+    buf[idx] = F::mul_add(p0[i], b, a);
+    buf[idx + h] = F::mul_add(p1[i], b, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise kernels of ENTER (src/fftree.rs:143-161) — level m, e = m/2, n/m blocks
+// ---------------------------------------------------------------------------------------------
+// work[j] = src[j] * winv0[j mod e]
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_scale_by_table(typename F::elem* dst,  // may alias src
+                                                            const typename F::elem* src,
+                                                            const typename F::elem* __restrict__ tbl,
+                                                            size_t tbl_mask, size_t n) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    dst[g] = F::mul(tbl[g & tbl_mask], src[g]);
+}
+
+// dst[b*m + 2i]   = u0[i] + xe[i]*v0[i]                (src block  = [u0 | v0])
+// dst[b*m + 2i+1] = w1[i]*U1[i] + w1x[i]*V1[i]         (work block = [U1 | V1], normalised)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __restrict__ dst,
+                                                           const typename F::elem* __restrict__ src,
+                                                           const typename F::elem* __restrict__ work,
+                                                           const typename F::elem* __restrict__ xe,
+                                                           const typename F::elem* __restrict__ w1,
+                                                           const typename F::elem* __restrict__ w1x,
+                                                           uint32_t log_e, size_t npairs) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= npairs) return;
+    size_t e = (size_t)1 << log_e;
+    size_t i = g & (e - 1);
+    size_t base = (g >> log_e) << (log_e + 1);
+    typename F::elem u0 = src[base + i], v0 = src[base + e + i];
+    typename F::elem U1 = work[base + i], V1 = work[base + e + i];
+    typename F::elem even = F::mul_add(xe[i], v0, u0);
+    typename F::elem odd = F::mul_add(w1x[i], V1, F::mul(w1[i], U1));
+    dst[base + 2 * i] = even;
+    dst[base + 2 * i + 1] = odd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise kernels of EXIT (src/fftree.rs:200-224, 232-259, 277-281) — level m, e = m/2.
+// cur is n elements in blocks of m (leaf order of T_m); G, H are n/2-element work arrays holding
+// one length-e vector per block.
+// ---------------------------------------------------------------------------------------------
+// G[b*e+i] = cur[b*m+2i] * A1[i]                       (t0 = e0/a0, pre-normalised)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_exit_pre1(typename F::elem* __restrict__ G,
+                                                       const typename F::elem* __restrict__ cur,
+                                                       const typename F::elem* __restrict__ A1,
+                                                       uint32_t log_e, size_t nhalf) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nhalf) return;
+    size_t i = g & (((size_t)1 << log_e) - 1);
+    G[g] = F::mul(A1[i], cur[2 * g]);
+}
+// H[g] = G[g] = cur[2g+1]*B1[i] + G[g]*NB2[i]          (h1 of the first REDC, normalised for S1->S0)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_exit_mid1(typename F::elem* G,
+                                                       typename F::elem* __restrict__ H,
+                                                       const typename F::elem* __restrict__ cur,
+                                                       const typename F::elem* __restrict__ B1,
+                                                       const typename F::elem* __restrict__ NB2,
+                                                       uint32_t log_e, size_t nhalf) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nhalf) return;
+    size_t i = g & (((size_t)1 << log_e) - 1);
+    typename F::elem r = F::mul_add(NB2[i], G[g], F::mul(B1[i], cur[2 * g + 1]));
+    G[g] = r;
+    H[g] = r;
+}
+// G[g] = H[g]*D1[i] + G[g]*NB2[i]                      (h1 of the second REDC)
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_exit_mid2(typename F::elem* G,
+                                                       const typename F::elem* __restrict__ H,
+                                                       const typename F::elem* __restrict__ D1,
+                                                       const typename F::elem* __restrict__ NB2,
+                                                       uint32_t log_e, size_t nhalf) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nhalf) return;
+    size_t i = g & (((size_t)1 << log_e) - 1);
+    G[g] = F::mul_add(NB2[i], G[g], F::mul(D1[i], H[g]));
+}
+// u0 = G*w0 ; v0 = (cur[2g] - u0)*xie ; dst block = [u0 | v0]
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_exit_split(typename F::elem* __restrict__ dst,
+                                                        const typename F::elem* __restrict__ cur,
+                                                        const typename F::elem* __restrict__ G,
+                                                        const typename F::elem* __restrict__ w0,
+                                                        const typename F::elem* __restrict__ xie,
+                                                        uint32_t log_e, size_t nhalf) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= nhalf) return;
+    size_t e = (size_t)1 << log_e;
+    size_t i = g & (e - 1);
+    size_t base = (g >> log_e) << (log_e + 1);
+    typename F::elem u0 = F::mul(w0[i], G[g]);
+    typename F::elem v0 = F::mul(xie[i], F::sub(cur[2 * g], u0));
+    dst[base + i] = u0;
+    dst[base + e + i] = v0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic element-wise helper for tree construction: functor(i) for i < n
+// ---------------------------------------------------------------------------------------------
+template <class Fn>
+__global__ __launch_bounds__(kBlock) void k_foreach(Fn fn, size_t n) {
+    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g < n) fn(g);
+}
+
+}  // namespace ecfft

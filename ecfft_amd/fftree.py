@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's `FFTree<F>` / `FftreeField` surface over the C-ABI library.
+
+Reference interface mirrored (names, argument meaning, error behaviour):
+    trait FftreeField { fn build_fftree(n) -> Option<FFTree<Self>> }      /root/reference/src/lib.rs:14-16
+    enum Moiety { S0, S1 }                                                 src/fftree.rs:17-21
+    FFTree::{new, extend, enter, exit, subtree_with_size} + pub tables     src/fftree.rs:24-38, 42, 123, 164, 227, 489
+
+Elements are passed in the crate's in-memory representation (secp256k1: uint64[n, 4] Montgomery limbs;
+m31: uint32[n]) as numpy arrays (host) or torch CUDA tensors (device-resident, zero copy).  Where the
+reference panics this raises: ValueError("FFTree is too small") / AssertionError for non powers of two.
+There is no CPU fallback: if libecfft_hip.so or a HIP device is missing the call fails loudly.
+"""
+import ctypes
+import enum
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+OK, ERR_NOT_POW2, ERR_TREE_TOO_SMALL, ERR_TREE_TOO_LARGE, ERR_HIP, ERR_BAD_ARG = range(6)
+MEM_HOST, MEM_DEVICE = 0, 1
+TBL_F, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV_S0, TBL_Z0Z0, TBL_Z1Z1 = 0, 3, 4, 5, 6, 7, 8, 9, 10
+
+EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_ctx_destroy", "ecfft_tree_size",
+           "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
+           "ecfft_device_info"]
+
+
+class Moiety(enum.IntEnum):
+    S0 = 0
+    S1 = 1
+
+
+class EcfftError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads (building if needed) the HIP extension.  Raises if it cannot be built or loaded."""
+    global _lib
+    if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; load it FIRST so that this
+        # library binds to the same HIP runtime instance (two runtimes in one process cannot share the
+        # GPU: torch then reports "No HIP GPUs are available").  Plain C users link /opt/rocm directly.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        path = os.path.join(_DIR, "libecfft_hip.so")
+        if not os.path.exists(path):
+            _build.build()
+        L = ctypes.CDLL(path)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.ecfft_elem_size.restype, L.ecfft_elem_size.argtypes = sz, [ci]
+        L.ecfft_build_fftree.restype, L.ecfft_build_fftree.argtypes = ci, [ci, sz, ci, ctypes.POINTER(vp)]
+        L.ecfft_fftree_new.restype, L.ecfft_fftree_new.argtypes = ci, [ci, vp, sz, vp, vp, ci, ctypes.POINTER(vp)]
+        L.ecfft_ctx_destroy.restype, L.ecfft_ctx_destroy.argtypes = None, [vp]
+        L.ecfft_tree_size.restype, L.ecfft_tree_size.argtypes = sz, [vp]
+        L.ecfft_field.restype, L.ecfft_field.argtypes = ci, [vp]
+        L.ecfft_enter.restype, L.ecfft_enter.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+        L.ecfft_exit.restype, L.ecfft_exit.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+        L.ecfft_extend.restype, L.ecfft_extend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
+        L.ecfft_tree_table.restype, L.ecfft_tree_table.argtypes = ci, [vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
+        L.ecfft_build_points.restype, L.ecfft_build_points.argtypes = ci, [ci, sz, vp, vp, vp]
+        L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc == OK:
+        return
+    if rc == ERR_NOT_POW2:
+        raise AssertionError("length must be a power of two")        # assert!(n.is_power_of_two())
+    if rc == ERR_TREE_TOO_SMALL:
+        raise ValueError("FFTree is too small")                        # panic!("FFTree is too small")
+    if rc == ERR_HIP:
+        raise EcfftError("HIP failure (no usable MI355X device, or a runtime error) — there is no CPU fallback")
+    raise EcfftError(f"ecfft error {rc}")
+
+
+class Field:
+    """One of the reference's two `FftreeField` implementors."""
+
+    def __init__(self, name, field_id, dtype, limbs):
+        self.name, self.id, self.dtype, self.limbs = name, field_id, np.dtype(dtype), limbs
+
+    @property
+    def elem_bytes(self):
+        return self.dtype.itemsize * self.limbs
+
+    def shape(self, n):
+        return (n, self.limbs) if self.limbs > 1 else (n,)
+
+    def build_fftree(self, n, device=0):
+        """`F::build_fftree(n)`: None if n exceeds the curve's 2-adicity (src/lib.rs:62-64, src/ec.rs:513-515)."""
+        h = ctypes.c_void_p()
+        rc = lib().ecfft_build_fftree(self.id, n, device, ctypes.byref(h))
+        if rc == ERR_TREE_TOO_LARGE:
+            return None
+        _check(rc)
+        return FFTree(self, h, device)
+
+    def build_points(self, n):
+        """host-only: (f[2n], map_num[log n, 3], map_den[log n, 3]) — leaves are f[n:]."""
+        ln = max(n.bit_length() - 1, 0)
+        f = np.zeros(self.shape(2 * n), self.dtype)
+        num = np.zeros(self.shape(3 * max(ln, 1)), self.dtype)
+        den = np.zeros(self.shape(3 * max(ln, 1)), self.dtype)
+        rc = lib().ecfft_build_points(self.id, n, f.ctypes.data, num.ctypes.data, den.ctypes.data)
+        if rc == ERR_TREE_TOO_LARGE:
+            return None
+        _check(rc)
+        return f, num[:3 * ln], den[:3 * ln]
+
+    def new_fftree(self, leaves, map_num, map_den, device=0):
+        """`FFTree::new(leaves, rational_maps)` (src/fftree.rs:42-70)."""
+        leaves = np.ascontiguousarray(leaves, self.dtype)
+        map_num = np.ascontiguousarray(map_num, self.dtype); map_den = np.ascontiguousarray(map_den, self.dtype)
+        n = leaves.shape[0]
+        h = ctypes.c_void_p()
+        _check(lib().ecfft_fftree_new(self.id, leaves.ctypes.data, n, map_num.ctypes.data, map_den.ctypes.data, device, ctypes.byref(h)))
+        return FFTree(self, h, device)
+
+
+secp256k1 = Field("secp256k1", 0, np.uint64, 4)
+m31 = Field("m31", 1, np.uint32, 1)
+FIELDS = {"secp256k1": secp256k1, "m31": m31}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class FFTree:
+    """Device-resident `FFTree<F>` (whole subtree chain).  `&self` methods, immutable after build."""
+
+    def __init__(self, field, handle, device):
+        self.field, self._h, self.device = field, handle, device
+        self.n = lib().ecfft_tree_size(handle)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ecfft_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- plumbing --------------------------------------------------------------------------
+    def _io(self, x, out_like=True):
+        """returns (in_ptr, out_obj, out_ptr, mem, stream, count_elems)"""
+        if _is_torch(x):
+            import torch
+            assert x.is_cuda and x.is_contiguous(), "device tensors must be contiguous CUDA tensors"
+            out = torch.empty_like(x)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            return x.data_ptr(), out, out.data_ptr(), MEM_DEVICE, stream, x.shape[0]
+        a = np.ascontiguousarray(x, self.field.dtype)
+        out = np.empty_like(a)
+        return a.ctypes.data, out, out.ctypes.data, MEM_HOST, None, a.shape[0]
+
+    # ---- the path --------------------------------------------------------------------------
+    def enter(self, coeffs):
+        """coefficients -> evaluations on the leaves of T_len (src/fftree.rs:164-167)."""
+        pin, out, pout, mem, stream, n = self._io(coeffs)
+        _check(lib().ecfft_enter(self._h, pin, pout, n, mem, stream))
+        return out
+
+    def exit(self, evals):
+        """evaluations -> coefficients (src/fftree.rs:227-230)."""
+        pin, out, pout, mem, stream, n = self._io(evals)
+        _check(lib().ecfft_exit(self._h, pin, pout, n, mem, stream))
+        return out
+
+    def extend(self, evals, moiety, count=1):
+        """extends evaluations onto the TARGET moiety (src/fftree.rs:123-126); `count` > 1 treats the
+        input as that many vectors laid end to end (batched form, no reference counterpart)."""
+        pin, out, pout, mem, stream, total = self._io(evals)
+        assert total % count == 0
+        _check(lib().ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
+        return out
+
+    # ---- pub fields ------------------------------------------------------------------------
+    def table(self, which, m=None):
+        m = self.n if m is None else m
+        cnt = ctypes.c_size_t()
+        _check(lib().ecfft_tree_table(self._h, m, which, None, 0, ctypes.byref(cnt)))
+        out = np.zeros(self.field.shape(cnt.value), self.field.dtype)
+        _check(lib().ecfft_tree_table(self._h, m, which, out.ctypes.data, cnt.value, ctypes.byref(cnt)))
+        return out
+
+    def leaves(self, m=None):
+        m = self.n if m is None else m
+        return self.table(TBL_F, m)[m:]
+
+    def subtree_with_size(self, n):
+        """src/fftree.rs:489-496 — the chain lives in one context, so this is a size check + view."""
+        assert n > 0 and n & (n - 1) == 0
+        if n > self.n:
+            raise ValueError("FFTree is too small")
+        return _SubtreeView(self, n)
+
+
+class _SubtreeView:
+    def __init__(self, tree, n):
+        self.tree, self.n = tree, n
+
+    def leaves(self):
+        return self.tree.leaves(self.n)
+
+    def table(self, which):
+        return self.tree.table(which, self.n)
+
+    def enter(self, c):
+        if len(c) > self.n:
+            raise ValueError("FFTree is too small")
+        return self.tree.enter(c)
+
+    def exit(self, e):
+        if len(e) > self.n:
+            raise ValueError("FFTree is too small")
+        return self.tree.exit(e)
+
+
+def device_info(device=0):
+    buf = ctypes.create_string_buffer(256)
+    lib().ecfft_device_info(device, buf, 256)
+    return buf.value.decode()

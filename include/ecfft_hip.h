@@ -1,0 +1,101 @@
+/* ecfft_hip.h — C ABI of the MI355X (gfx950) ECFFT hot path.
+ *
+ * Drop-in boundary for the EXTEND / ENTER / EXIT path of andrewmilson/ecfft.  The reference has no
+ * FFI layer (pure generic Rust); each entry point below names the Rust item whose body a thin
+ * `impl` would forward to it (see INTEGRATION.md for the binding a maintainer would add):
+ *
+ *   ecfft_build_fftree            <-> FftreeField::build_fftree(n) -> Option<FFTree<Self>>   src/lib.rs:14-16, 39-85, 198-215
+ *   ecfft_fftree_new              <-> FFTree::new(leaves, rational_maps)                       src/fftree.rs:42-70
+ *   ecfft_enter                   <-> FFTree::enter(&self, &[F]) -> Vec<F>                     src/fftree.rs:164-167
+ *   ecfft_exit                    <-> FFTree::exit(&self, &[F]) -> Vec<F>                      src/fftree.rs:227-230
+ *   ecfft_extend                  <-> FFTree::extend(&self, &[F], Moiety) -> Vec<F>            src/fftree.rs:123-126
+ *   ecfft_tree_size / _table      <-> the pub fields of FFTree<F> / subtree_with_size          src/fftree.rs:24-38, 489-496
+ *   ecfft_ctx_destroy             <-> Drop
+ *
+ * Element representation = the crate's in-memory one, so Rust slices pass through untouched:
+ *   ECFFT_FIELD_SECP256K1: 32 bytes = [u64; 4] little-endian limbs of x * 2^256 mod p (ark-ff
+ *                          Fp256<MontBackend<FqConfig, 4>>, src/lib.rs:37), fully reduced;
+ *   ECFFT_FIELD_M31:       4 bytes  = u32 canonical residue (ark_ff_optimized::fp31::Fp, src/lib.rs:196).
+ * Outputs are fully reduced, so equality of bytes == equality of field elements (assert_eq! in the
+ * reference's tests).
+ *
+ * Errors: the reference panics (src/fftree.rs:40 "TODO: errors"); the ABI returns a status instead:
+ *   - length not a power of two   (assert!, src/fftree.rs:490, src/lib.rs:41)  -> ECFFT_ERR_NOT_POW2
+ *   - "FFTree is too small"       (panic!, src/fftree.rs:494)                   -> ECFFT_ERR_TREE_TOO_SMALL
+ *   - build_fftree returning None (src/lib.rs:62-64, src/ec.rs:513-515)         -> ECFFT_ERR_TREE_TOO_LARGE, *out = NULL
+ * There is no CPU fallback: without a usable HIP device every call fails with ECFFT_ERR_HIP.
+ *
+ * Threading: a context is immutable after creation (like &FFTree); transform calls on one context
+ * serialise on its scratch buffers; use one context per host thread/stream for concurrency.
+ * Ownership: the caller owns every buffer; `stream` is a hipStream_t passed as void* (NULL = default).
+ */
+#ifndef ECFFT_HIP_H
+#define ECFFT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ecfft_ctx ecfft_ctx;
+
+enum { ECFFT_FIELD_SECP256K1 = 0, ECFFT_FIELD_M31 = 1 };
+enum { ECFFT_S0 = 0, ECFFT_S1 = 1 };                 /* enum Moiety, src/fftree.rs:17-21 (the TARGET moiety) */
+enum { ECFFT_MEM_HOST = 0, ECFFT_MEM_DEVICE = 1 };   /* where in/out pointers live */
+enum {
+    ECFFT_OK = 0,
+    ECFFT_ERR_NOT_POW2 = 1,
+    ECFFT_ERR_TREE_TOO_SMALL = 2,
+    ECFFT_ERR_TREE_TOO_LARGE = 3,
+    ECFFT_ERR_HIP = 4,
+    ECFFT_ERR_BAD_ARG = 5
+};
+/* tables of FFTree<F> exported by ecfft_tree_table (src/fftree.rs:25-37) */
+enum {
+    ECFFT_TBL_F = 0,              /* BinaryTree<F>, 2m entries, heap order          */
+    ECFFT_TBL_XNN_S = 3, ECFFT_TBL_XNN_S_INV = 4, ECFFT_TBL_Z0_S1 = 5, ECFFT_TBL_Z1_S0 = 6,
+    ECFFT_TBL_Z0_INV_S1 = 7, ECFFT_TBL_Z1_INV_S0 = 8, ECFFT_TBL_Z0Z0_REM_XNN_S = 9, ECFFT_TBL_Z1Z1_REM_XNN_S = 10
+};
+
+/* size in bytes of one field element of `field` (32 or 4); 0 for an unknown field */
+size_t ecfft_elem_size(int field);
+
+/* FftreeField::build_fftree(n): builds the whole subtree chain T_1..T_n on `device`. */
+int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out);
+
+/* FFTree::new(leaves, rational_maps): n leaves and log2(n) maps, each map given as 3 numerator and
+ * 3 denominator coefficients (low -> high, zero padded) — all in the element representation above. */
+int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_num3, const void* map_den3,
+                     int device, ecfft_ctx** out);
+
+void ecfft_ctx_destroy(ecfft_ctx* ctx);
+
+size_t ecfft_tree_size(const ecfft_ctx* ctx);   /* number of leaves of the top tree */
+int ecfft_field(const ecfft_ctx* ctx);
+
+/* coefficients -> evaluations on the leaves of T_n (n = len; any power of two <= tree size) */
+int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream);
+/* evaluations -> coefficients */
+int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int mem, void* stream);
+/* `count` vectors of `e` evaluations on the moiety opposite to `moiety` -> evaluations on `moiety`
+ * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend). */
+int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);
+
+/* copy one table of the subtree with m leaves into host memory (element representation above);
+ * returns the number of elements through *count; cap = capacity of host_out in elements. */
+int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);
+
+/* Host-only front end of build_fftree (src/lib.rs:66-81) + the layer fill of FFTree::new
+ * (src/fftree.rs:49-67): writes f (2n elements, heap order: f[n..2n) = leaves x(coset_offset + i*G))
+ * and the log2(n) isogeny x-maps (3 + 3 coefficients each).  Needs no GPU; used to cross-check the
+ * construction against an ark-built tree. */
+int ecfft_build_points(int field, size_t n, void* f_out, void* map_num3_out, void* map_den3_out);
+
+/* library / device identification for logs: writes a NUL-terminated string */
+int ecfft_device_info(int device, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

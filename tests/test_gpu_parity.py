@@ -1,0 +1,185 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(include/ecfft_hip.h via ecfft_amd.fftree), against the golden fixtures, the CPU oracle and
+size-independent properties.  Bit-exact: every comparison is array equality on the crate's
+in-memory element representation."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, std_to_field
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["secp256k1", "m31"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import ecfft_amd
+    ecfft_amd.lib()
+    return ecfft_amd
+
+
+_gpu_trees = {}
+
+
+@pytest.fixture(scope="module")
+def gpu_tree(gpu):
+    def get(field, n):
+        key = (field, n)
+        if key not in _gpu_trees:
+            t = gpu.FIELDS[field].build_fftree(n)
+            assert t is not None
+            _gpu_trees[key] = t
+        return _gpu_trees[key]
+    return get
+
+
+def rand_elems(F, n, seed):
+    rng = np.random.default_rng(seed)
+    if F.limbs == 1:
+        return rng.integers(0, 2**31 - 1, n, dtype=np.uint32)
+    p = 2**256 - 2**32 - 977
+    return F.from_ints([int.from_bytes(rng.bytes(32), "little") % p for _ in range(n)])
+
+
+# ------------------------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("n", [4, 64, 4096])
+def test_golden_enter_exit_extend(gpu, gpu_tree, oracle_mod, field, n):
+    F = oracle_mod.field(field)
+    t = gpu_tree(field, n)
+    g = load_golden(field, n)
+    coeffs, evals = std_to_field(F, g["enter_coeffs"]), std_to_field(F, g["enter_evals"])
+    assert np.array_equal(t.leaves(), std_to_field(F, g["leaves"]))
+    assert np.array_equal(t.enter(coeffs), evals)
+    assert np.array_equal(t.exit(evals), coeffs)
+    s0, s1 = std_to_field(F, g["extend_s0"]), std_to_field(F, g["extend_s1"])
+    assert np.array_equal(t.extend(s0, gpu.Moiety.S1), s1)
+    assert np.array_equal(t.extend(s1, gpu.Moiety.S0), s0)
+
+
+# ------------------------------------------------------------------------------------ vs the oracle
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 11, 13])
+def test_matches_oracle_random(gpu, gpu_tree, oracle_tree, oracle_mod, field, log_n):
+    n = 1 << log_n
+    F, ot = oracle_tree(field, 1 << 13)
+    t = gpu_tree(field, 1 << 13)          # bigger tree: exercises subtree_with_size (src/fftree.rs:489-496)
+    c = rand_elems(F, n, 100 + log_n)
+    ev = ot.enter(c)
+    assert np.array_equal(t.enter(c), ev)
+    assert np.array_equal(t.exit(ev), c)
+    r = rand_elems(F, n, 200 + log_n)     # EXIT of arbitrary evaluations (as benches/fftree.rs:32-34)
+    assert np.array_equal(t.exit(r), ot.exit(r))
+    if 2 * n <= t.n:
+        assert np.array_equal(t.extend(r, gpu.Moiety.S1), ot.extend(r, oracle_mod.S1))
+        assert np.array_equal(t.extend(r, gpu.Moiety.S0), ot.extend(r, oracle_mod.S0))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_tables_match_oracle(gpu, gpu_tree, oracle_tree, oracle_mod, field):
+    """the on-GPU precompute (from_tree, src/fftree.rs:318-463) reproduces every table of every subtree"""
+    F, ot = oracle_tree(field, 1 << 13)
+    t = gpu_tree(field, 1 << 13)
+    o = oracle_mod
+    pairs = [(gpu.TBL_F, o.T_F), (gpu.TBL_XNN_S, o.T_XNN_S), (gpu.TBL_XNN_S_INV, o.T_XNN_S_INV), (gpu.TBL_Z0_S1, o.T_Z0_S1),
+             (gpu.TBL_Z1_S0, o.T_Z1_S0), (gpu.TBL_Z0_INV_S1, o.T_Z0_INV_S1), (gpu.TBL_Z1_INV_S0, o.T_Z1_INV_S0),
+             (gpu.TBL_Z0Z0, o.T_Z0Z0), (gpu.TBL_Z1Z1, o.T_Z1Z1)]
+    for m in (2, 4, 8, 64, 1024, 8192):
+        for gw, ow in pairs:
+            a, b = t.table(gw, m), ot.table(ow, m)
+            if gw == gpu.TBL_F:
+                a, b = a[1:], b[1:]       # index 0 of the heap is unused
+            assert np.array_equal(a, b), (m, gw)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_batched_extend(gpu, gpu_tree, oracle_tree, oracle_mod, field):
+    F, ot = oracle_tree(field, 1 << 13)
+    t = gpu_tree(field, 1 << 13)
+    e, count = 256, 5
+    x = rand_elems(F, e * count, 31)
+    got = t.extend(x, gpu.Moiety.S1, count=count)
+    for v in range(count):
+        assert np.array_equal(got[v * e:(v + 1) * e], ot.extend(x[v * e:(v + 1) * e], oracle_mod.S1))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_fftree_new_from_leaves(gpu, oracle_tree, oracle_mod, field):
+    """FFTree::new(leaves, rational_maps) (src/fftree.rs:42-70) from an externally built point set"""
+    F, ot = oracle_tree(field, 64)
+    leaves = ot.leaves()
+    num = np.concatenate([ot.rational_map(k)[0] for k in range(6)])
+    den = np.concatenate([ot.rational_map(k)[1] for k in range(6)])
+    t = gpu.FIELDS[field].new_fftree(leaves, num, den)
+    c = rand_elems(F, 64, 5)
+    assert np.array_equal(t.enter(c), ot.enter(c))
+    assert np.array_equal(t.exit(ot.enter(c)), c)
+
+
+# ------------------------------------------------------------------------------------ edge cases / errors
+@pytest.mark.parametrize("field", FIELDS)
+def test_edge_cases(gpu, gpu_tree, oracle_mod, field):
+    F = oracle_mod.field(field)
+    t = gpu_tree(field, 64)
+    one = rand_elems(F, 1, 3)
+    assert np.array_equal(t.enter(one), one) and np.array_equal(t.exit(one), one)   # src/fftree.rs:145-147, 202-204
+    with pytest.raises(ValueError, match="FFTree is too small"):
+        t.enter(rand_elems(F, 128, 1))
+    with pytest.raises(ValueError, match="FFTree is too small"):
+        t.extend(rand_elems(F, 64, 1), gpu.Moiety.S1)                                # needs T_128
+    with pytest.raises(AssertionError):
+        t.enter(rand_elems(F, 48, 1))
+    zeros = np.zeros_like(rand_elems(F, 64, 1))
+    assert np.array_equal(t.enter(zeros), zeros) and np.array_equal(t.exit(zeros), zeros)
+    # maximal residues p-1
+    top = F.from_ints([(2**31 - 2) if F.limbs == 1 else (2**256 - 2**32 - 978)] * 64)
+    assert np.array_equal(t.exit(t.enter(top)), top)
+
+
+def test_device_resident_tensors(gpu, gpu_tree, oracle_tree):
+    """zero-copy device path: torch CUDA tensors in, torch CUDA tensors out, on torch's current stream"""
+    import torch
+    F, ot = oracle_tree("secp256k1", 1 << 13)
+    t = gpu_tree("secp256k1", 1 << 13)
+    c = rand_elems(F, 4096, 77)
+    d = torch.from_numpy(c.view(np.int64)).cuda()
+    ev = t.enter(d)
+    back = t.exit(ev)
+    torch.cuda.synchronize()
+    assert np.array_equal(ev.cpu().numpy().view(np.uint64), ot.enter(c))
+    assert np.array_equal(back.cpu().numpy().view(np.uint64), c)
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs
+def test_config2_secp_2e16_bit_exact_vs_cpu(gpu, gpu_tree, oracle_mod):
+    """BASELINE.json configs[1]: secp256k1 n=2^16 ENTER+EXIT, bit-exact vs the CPU path"""
+    F = oracle_mod.field("secp256k1")
+    ot = F.build_fftree(1 << 16)
+    t = gpu_tree("secp256k1", 1 << 16)
+    c = rand_elems(F, 1 << 16, 0x5EED0002)
+    ev = ot.enter(c)
+    assert np.array_equal(t.enter(c), ev)
+    assert np.array_equal(t.exit(ev), c)
+
+
+@pytest.mark.parametrize("field,log_n", [("secp256k1", 20), ("m31", 22)])
+def test_full_size_properties(gpu, gpu_tree, oracle_mod, field, log_n):
+    """BASELINE.json configs[2] size (secp256k1 n=2^20) through size-independent properties:
+    EXIT(ENTER(c)) == c, linearity, and spot checks of ENTER against naive Horner evaluation at
+    individual leaves (the oracle evaluates sum c_j x^j at a handful of points)."""
+    n = 1 << log_n
+    F = oracle_mod.field(field)
+    t = gpu_tree(field, n)
+    a, b = rand_elems(F, n, 1), rand_elems(F, n, 2)
+    ea, eb = t.enter(a), t.enter(b)
+    assert np.array_equal(t.exit(ea), a)
+    assert np.array_equal(t.enter(F.add(a, b)), F.add(ea, eb))
+    leaves = t.leaves()
+    idx = np.array([0, 1, 2, n // 2 - 1, n // 2, n - 2, n - 1, 12345 % n, 777777 % n])
+    assert np.array_equal(ea[idx], F.horner(a, leaves[idx]))
+    # EXTEND at the top size: evaluations of a degree < n/2 polynomial on S0 -> S1
+    lo = a.copy(); lo[n // 2:] = 0
+    el = t.enter(lo)
+    assert np.array_equal(t.extend(el[0::2].copy(), gpu.Moiety.S1), el[1::2])
+    assert np.array_equal(t.extend(el[1::2].copy(), gpu.Moiety.S0), el[0::2])
