@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on MI355X: secp256k1 Fp field-mul/s and ENTER+EXIT wall time at n=2^20.
+
+One "step" = one ENTER followed by one EXIT of a degree-(n-1) polynomial with synthetic (seeded,
+uniform) coefficients that are already resident in HBM when the timed region starts.  field-mul/s
+uses the ALGORITHMIC multiplication count of the reference's recursion:
+    W_mul(ENTER) = 2nL(L-1) + nL,   W_mul(EXIT) = 4nL(L-1) + 4.5nL,   L = log2 n
+independent of how this implementation re-associates the arithmetic.
+
+Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
+the path shards over independent polynomials, one per GPU, no data-path collective (weak scaling);
+RCCL is used only for the barrier and the max-over-ranks of the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+P_SECP = 2**256 - 2**32 - 977
+
+
+def w_mul(n):
+    L = n.bit_length() - 1
+    return 2 * n * L * (L - 1) + n * L, 4 * n * L * (L - 1) + 4.5 * n * L
+
+
+def b_alg(n, s):
+    L = n.bit_length() - 1
+    enter = s * (2 * n * L * (L - 1) + 8 * (n - 1 - L) + 3 * n * L + 2 * (n - 1))
+    exit_ = s * (4 * n * L * (L - 1) + 32 * (n - 1 - L) + 8.5 * n * L + 8.5 * (n - 1))
+    return enter, exit_
+
+
+def synth(field, n, seed):
+    """seeded uniform field elements in the crate's in-memory representation (host numpy)"""
+    rng = np.random.default_rng(seed)
+    if field == "m31":
+        return rng.integers(0, 2**31 - 1, n, dtype=np.uint32)
+    # uniform 256-bit words, rejection of values >= p is a 2^-223 event: clamp by clearing on collision
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    bad = (a[:, 3] == 0xFFFFFFFFFFFFFFFF) & (a[:, 2] == 0xFFFFFFFFFFFFFFFF) & (a[:, 1] == 0xFFFFFFFFFFFFFFFF) & (a[:, 0] >= 0xFFFFFFFEFFFFFC2F)
+    a[bad, 0] = 0
+    return a   # any canonical 256-bit pattern < p is a valid Montgomery-form element
+
+
+def cpu_baseline(field, log_n):
+    """the oracle (C restatement of the reference's recursive single-threaded algorithm, incl. its
+    per-REDC batch inversion) timed on this host on a bounded sample: one ENTER + EXIT at 2^log_n."""
+    from oracle import oracle
+    F = oracle.field(field)
+    n = 1 << log_n
+    t = F.build_fftree(n)
+    c = synth(field, n, 0xC0FFEE)
+    t0 = time.perf_counter(); ev = t.enter(c); t1 = time.perf_counter(); back = t.exit(ev); t2 = time.perf_counter()
+    assert np.array_equal(back, c)
+    we, wx = w_mul(n)
+    return {"value": (we + wx) / (t2 - t0), "unit": "field-mul/s", "cores": 1, "kind": "port",
+            "sample": f"{field} n=2^{log_n} one ENTER ({t1 - t0:.3f}s) + one EXIT ({t2 - t1:.3f}s), oracle/ C restatement, 1 thread",
+            "host_cpu": _cpu_name()}
+
+
+def _cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--field", default="secp256k1", choices=["secp256k1", "m31"])
+    ap.add_argument("--cpu-log-n", type=int, default=15, help="size of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
+    args = ap.parse_args()
+
+    import torch
+    import ecfft_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.log_n
+    F = ecfft_amd.FIELDS[args.field]
+    t_build0 = time.perf_counter()
+    tree = F.build_fftree(n, device=local_rank)
+    if tree is None:
+        raise SystemExit("n exceeds the curve's 2-adicity")
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build0
+
+    host = synth(args.field, n, 0x5EED0000 + 2 + rank)
+    view = host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)
+    coeffs = torch.from_numpy(view).cuda()          # resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        ev = tree.enter(coeffs)
+        return ev, tree.exit(ev)
+
+    for _ in range(args.warmup):
+        ev, back = step()
+    barrier()
+    if args.warmup:
+        assert torch.equal(back, coeffs), "EXIT(ENTER(c)) != c"
+
+    # ---- timed region: exactly K steps --------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev, back = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.equal(back, coeffs), "EXIT(ENTER(c)) != c"
+
+    # ---- per-kernel HIP-event pass over the same K steps (events on the launch stream) -----------
+    roofline = None
+    split = {}
+    if not args.no_profile and args.steps > 0:
+        tree.profile(True)
+        te0 = time.perf_counter()
+        for _ in range(args.steps):
+            ev = tree.enter(coeffs)
+        torch.cuda.synchronize(); te1 = time.perf_counter()
+        for _ in range(args.steps):
+            back = tree.exit(ev)
+        torch.cuda.synchronize(); te2 = time.perf_counter()
+        classes = tree.profile_read()
+        tree.profile(False)
+        split = {"enter_ms": (te1 - te0) * 1e3 / args.steps, "exit_ms": (te2 - te1) * 1e3 / args.steps,
+                 "instrumented_ms_per_step": (te2 - te0) * 1e3 / args.steps}
+        tot_alg = sum(c["alg_bytes"] for c in classes)
+        dom = max(classes, key=lambda c: c["ms"])
+        if dom["launches"]:
+            ach = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": _traffic(dom["name"]),
+                        "launches_per_step": dom["launches"] / args.steps,
+                        "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
+                        "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
+                        "share_of_event_time": dom["ms"] / max(sum(c["ms"] for c in classes), 1e-12),
+                        "whole_job_alg_GBs": sum(b_alg(n, F.elem_bytes)) / (elapsed / args.steps) / 1e9,
+                        "kernels": [{k: c[k] for k in ("name", "launches", "ms", "alg_bytes")} for c in classes if c["launches"]]}
+            be, bx = b_alg(n, F.elem_bytes)
+            roofline["alg_bytes_check"] = {"profiler_sum_per_step": tot_alg / args.steps, "closed_form": be + bx}
+
+    if rank == 0:
+        we, wx = w_mul(n)
+        value = (we + wx) * args.steps * world / elapsed
+        out = {
+            "metric": f"{args.field} Fp field-mul/s, ENTER+EXIT at n=2^{args.log_n}",
+            "value": value, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+            "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT (BASELINE.json configs[2])" if args.log_n == 20 and args.field == "secp256k1"
+                       else f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT",
+                       "n": n, "field": args.field, "parallelism": f"{world} independent polynomial(s), one per GPU, no collective",
+                       "inputs": "device-resident (HBM) before the timed region", "tree_build_s": build_s},
+            "roofline": roofline,
+            "cpu_baseline": None,
+        }
+        out.update(split)
+        if world == 1 and args.cpu_log_n > 0:
+            out["cpu_baseline"] = cpu_baseline(args.field, args.cpu_log_n)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _traffic(kernel):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), else None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

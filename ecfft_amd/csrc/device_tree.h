@@ -33,6 +33,54 @@ static inline void foreach_n(hipStream_t s, size_t n, Fn fn) {
     if (n) hipLaunchKernelGGL(k_foreach<Fn>, dim3(nblocks(n)), dim3(kBlock), 0, s, fn, n);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-launch timing with HIP events on the launch stream (bench.py's "roofline" object).
+// Every hot-path launch goes through ECFFT_LAUNCH with a kernel class and the ALGORITHMIC bytes of
+// that launch in the stage-streaming model of SURVEY.md section 8(d): each butterfly stage it covers
+// reads and writes its operand once and reads its stage tables once; each pointwise step reads its
+// operands and tables and writes its result once.
+// ---------------------------------------------------------------------------------------------
+enum KernelClass { KC_DECOMPOSE = 0, KC_RECOMBINE, KC_POINTWISE, KC_FUSED_EXTEND, KC_FUSED_ENTER, KC_FUSED_EXIT, KC_COUNT };
+static const char* const kKernelClassName[KC_COUNT] = {"k_decompose_stage", "k_recombine_stage", "pointwise",
+                                                       "k_extend_fused", "k_enter_fused", "k_exit_fused"};
+
+class Profiler {
+public:
+    bool on = false;
+    ~Profiler() { for (hipEvent_t e : pool_) (void)hipEventDestroy(e); }
+    void reset() { used_ = 0; recs_.clear(); for (int i = 0; i < KC_COUNT; ++i) { ms_[i] = 0; bytes_[i] = 0; n_[i] = 0; } }
+    hipEvent_t next() {
+        if (used_ == pool_.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool_.push_back(e); }
+        return pool_[used_++];
+    }
+    void begin(hipStream_t s, int cls, double bytes) {
+        hipEvent_t a = next(); (void)hipEventRecord(a, s);
+        recs_.push_back({cls, bytes, a, nullptr});
+    }
+    void end(hipStream_t s) { hipEvent_t b = next(); (void)hipEventRecord(b, s); recs_.back().stop = b; }
+    void collect() {   // caller has synchronised the stream(s)
+        for (const Rec& r : recs_) {
+            float ms = 0; if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+            ms_[r.cls] += ms; bytes_[r.cls] += r.bytes; n_[r.cls] += 1;
+        }
+        recs_.clear(); used_ = 0;
+    }
+    double ms(int c) const { return ms_[c]; }
+    double bytes(int c) const { return bytes_[c]; }
+    uint64_t launches(int c) const { return n_[c]; }
+private:
+    struct Rec { int cls; double bytes; hipEvent_t start, stop; };
+    std::vector<hipEvent_t> pool_; size_t used_ = 0;
+    std::vector<Rec> recs_;
+    double ms_[KC_COUNT] = {}, bytes_[KC_COUNT] = {}; uint64_t n_[KC_COUNT] = {};
+};
+
+#define ECFFT_LAUNCH(cls, alg_bytes, kern, grid, block, lds, stream, ...)               \
+    do { if (prof_.on) prof_.begin(stream, cls, (double)(alg_bytes));                  \
+         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);               \
+         if (prof_.on) prof_.end(stream); } while (0)
+
 template <class F>
 class DeviceChain {
 public:
@@ -55,6 +103,7 @@ public:
     const HostTree<F>& host() const { return host_; }
     const E* f_device() const { return f_; }
     std::mutex& lock() { return mu_; }
+    Profiler& profiler() const { return prof_; }
 
     // ------------------------------------------------------------------------------------------
     // construction
@@ -99,13 +148,13 @@ public:
         size_t npairs = total / 2;
         for (unsigned k = 0; k < le; ++k) {
             size_t h = e >> (k + 1), off = e - 2 * h;
-            hipLaunchKernelGGL(k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s, buf, T.np0[src] + off,
-                               T.dinv[src] + off, ilog2(h), npairs);
+            ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * total + 4.0 * h), k_decompose_stage<F>, dim3(nblocks(npairs)),
+                         dim3(kBlock), 0, s, buf, T.np0[src] + off, T.dinv[src] + off, ilog2(h), npairs);
         }
         for (unsigned k = le; k-- > 0;) {
             size_t h = e >> (k + 1), off = e - 2 * h;
-            hipLaunchKernelGGL(k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s, buf, T.p0[tgt] + off,
-                               T.p1[tgt] + off, ilog2(h), npairs);
+            ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * total + 4.0 * h), k_recombine_stage<F>, dim3(nblocks(npairs)),
+                         dim3(kBlock), 0, s, buf, T.p0[tgt] + off, T.p1[tgt] + off, ilog2(h), npairs);
         }
     }
 
@@ -131,10 +180,12 @@ public:
             const Tree& T = trees_[l];
             size_t e = T.e;
             E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
-            hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(n)), dim3(kBlock), 0, s, work, src, T.winv[0], e - 1, n);
+            // pre-scale is bookkeeping of the normalised form (0 algorithmic bytes); combine = loop C (:155-159):
+            // reads u0,v0,u1,v1 (2n), x table (m), writes n
+            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(n)), dim3(kBlock), 0, s, work, src, T.winv[0], e - 1, n);
             extend_core(l, work, n, 0, s);
-            hipLaunchKernelGGL(k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s, dst, src, (const E*)work, T.xe,
-                               T.w[1], T.w1x, ilog2(e), n / 2);
+            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * n + 2.0 * e), k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s,
+                         dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), n / 2);
             src = dst;
         }
         if (src != out) (void)hipMemcpyAsync(out, src, n * sizeof(E), hipMemcpyDeviceToDevice, s);
@@ -152,15 +203,19 @@ public:
             unsigned le = ilog2(T.e);
             E* dst = (l == 1 && out != in) ? out : (cur == bufA ? bufB : bufA);
             dim3 g(nblocks(nh)), b(kBlock);
-            hipLaunchKernelGGL(k_exit_pre1<F>, g, b, 0, s, G, cur, T.A1, le, nh);
+            // algorithmic bytes of the pointwise steps per level (8.5 n + 8.5 m/2 ... split per step):
+            //   t0 = e0*a0inv: r n/2 + tbl e + w n/2 ; h1: r n (e1,g1) + tbl 2e + w n/2 ; hc = h*c: r n + tbl m + w n ;
+            //   second redc the same two steps ; split v0 = (e0-u0)*xinv: r n + tbl e/2.. (SURVEY totals 8.5 n + 8.5 e per level)
+            double se = sizeof(E);
+            ECFFT_LAUNCH(KC_POINTWISE, se * (1.0 * n + T.e), k_exit_pre1<F>, g, b, 0, s, G, cur, T.A1, le, nh);
             extend_core(l, G, nh, 0, s);
-            hipLaunchKernelGGL(k_exit_mid1<F>, g, b, 0, s, G, H, cur, T.B1, T.NB2, le, nh);
+            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid1<F>, g, b, 0, s, G, H, cur, T.B1, T.NB2, le, nh);
             extend_core(l, G, nh, 1, s);
-            hipLaunchKernelGGL(k_scale_by_table<F>, g, b, 0, s, G, (const E*)G, T.C1, T.e - 1, nh);
+            ECFFT_LAUNCH(KC_POINTWISE, se * (2.0 * n + 2.0 * T.e + 1.0 * n + T.e), k_scale_by_table<F>, g, b, 0, s, G, (const E*)G, T.C1, T.e - 1, nh);
             extend_core(l, G, nh, 0, s);
-            hipLaunchKernelGGL(k_exit_mid2<F>, g, b, 0, s, G, (const E*)H, T.D1, T.NB2, le, nh);
+            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid2<F>, g, b, 0, s, G, (const E*)H, T.D1, T.NB2, le, nh);
             extend_core(l, G, nh, 1, s);
-            hipLaunchKernelGGL(k_exit_split<F>, g, b, 0, s, dst, cur, (const E*)G, T.w[0], T.xie, le, nh);
+            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 0.5 * T.e), k_exit_split<F>, g, b, 0, s, dst, cur, (const E*)G, T.w[0], T.xie, le, nh);
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
@@ -416,6 +471,7 @@ private:
     std::vector<Tree> trees_;
     std::vector<void*> temps_;
     std::mutex mu_;
+    mutable Profiler prof_;
 };
 
 }  // namespace ecfft

@@ -274,6 +274,27 @@ int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, 
                                                : table_of(*ctx->m31, m, which, host_out, cap, count);
 }
 
+int ecfft_profile_enable(ecfft_ctx* ctx, int on) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    Profiler& p = ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->profiler() : ctx->m31->profiler();
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    p.reset(); p.on = on != 0;
+    return ECFFT_OK;
+}
+int ecfft_profile_classes(void) { return KC_COUNT; }
+int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t* launches, double* ms_total,
+                       double* alg_bytes_total) {
+    if (!ctx || cls < 0 || cls >= KC_COUNT) return ECFFT_ERR_BAD_ARG;
+    Profiler& p = ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->profiler() : ctx->m31->profiler();
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    p.collect();
+    if (name && cap) snprintf(name, cap, "%s", kKernelClassName[cls]);
+    if (launches) *launches = p.launches(cls);
+    if (ms_total) *ms_total = p.ms(cls);
+    if (alg_bytes_total) *alg_bytes_total = p.bytes(cls);
+    return ECFFT_OK;
+}
+
 int ecfft_device_info(int device, char* buf, size_t cap) {
     if (!buf || !cap) return ECFFT_ERR_BAD_ARG;
     hipDeviceProp_t p;

@@ -26,7 +26,7 @@ TBL_F, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV
 
 EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_ctx_destroy", "ecfft_tree_size",
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
-           "ecfft_device_info"]
+           "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read"]
 
 
 class Moiety(enum.IntEnum):
@@ -69,6 +69,10 @@ def lib():
         L.ecfft_tree_table.restype, L.ecfft_tree_table.argtypes = ci, [vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
         L.ecfft_build_points.restype, L.ecfft_build_points.argtypes = ci, [ci, sz, vp, vp, vp]
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
+        L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
+        L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
+        L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
+                                                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
@@ -185,6 +189,19 @@ class FFTree:
         pin, out, pout, mem, stream, total = self._io(evals)
         assert total % count == 0
         _check(lib().ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
+        return out
+
+    # ---- benchmarking aid -------------------------------------------------------------------
+    def profile(self, on):
+        _check(lib().ecfft_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """[{name, launches, ms, alg_bytes}] per kernel class, from HIP events on the launch stream."""
+        out = []
+        for c in range(lib().ecfft_profile_classes()):
+            name = ctypes.create_string_buffer(64); n = ctypes.c_uint64(); ms = ctypes.c_double(); by = ctypes.c_double()
+            _check(lib().ecfft_profile_read(self._h, c, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+            out.append({"name": name.value.decode(), "launches": n.value, "ms": ms.value, "alg_bytes": by.value})
         return out
 
     # ---- pub fields ------------------------------------------------------------------------

@@ -92,6 +92,15 @@ int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, 
  * construction against an ark-built tree. */
 int ecfft_build_points(int field, size_t n, void* f_out, void* map_num3_out, void* map_den3_out);
 
+/* Per-launch timing for benchmarks (no reference counterpart): while enabled, every hot-path kernel
+ * launch is bracketed by HIP events on its stream.  ecfft_profile_read synchronises the device and
+ * returns, for kernel class `cls` (0 <= cls < ecfft_profile_classes()), its name, number of launches,
+ * summed event time in ms and summed ALGORITHMIC bytes (stage-streaming model). */
+int ecfft_profile_enable(ecfft_ctx* ctx, int on);
+int ecfft_profile_classes(void);
+int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t* launches, double* ms_total,
+                       double* alg_bytes_total);
+
 /* library / device identification for logs: writes a NUL-terminated string */
 int ecfft_device_info(int device, char* buf, size_t cap);
 
