@@ -141,21 +141,50 @@ public:
     // EXTEND core: all 2*log(e) normalised stages, in place, on `total` elements = count vectors
     // of length e = m/2 laid end to end.  src = parity of the moiety the data lives on.
     // ------------------------------------------------------------------------------------------
-    void extend_core(unsigned log_m, E* buf, size_t total, int src, hipStream_t s) const {
+    // pre/post: optional per-position tables (indexed pos mod e) multiplied in on the way in / out.
+    // in may differ from buf (out-of-place first touch).  Stages whose pair distance does not fit the
+    // LDS tile stream through HBM one launch per stage; the rest run fused in k_stages_lds.
+    static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? 11 : 14;     // 64 KiB of LDS
+    void extend_core(unsigned log_m, const E* in, E* buf, size_t total, int src, const E* pre, const E* post, hipStream_t s,
+                     double extra_alg_bytes = 0.0) const {
         const Tree& T = trees_[log_m];
         size_t e = T.e; unsigned le = ilog2(e);
         int tgt = 1 - src;
         size_t npairs = total / 2;
-        for (unsigned k = 0; k < le; ++k) {
+        unsigned tz = (unsigned)__builtin_ctzll((unsigned long long)total);   // tiles must divide count*e
+        unsigned log_tile = tz < kLogTileMax ? tz : kLogTileMax;
+        // first fused stage: 2h <= tile  <=>  le - k <= log_tile
+        unsigned k_first = le > log_tile ? le - log_tile : 0;
+        const E* cur_in = in;
+        if (k_first > 0 && (pre || in != buf)) {
+            if (pre) { ECFFT_LAUNCH(KC_POINTWISE, extra_alg_bytes, k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, buf, in, pre, e - 1, total); extra_alg_bytes = 0.0; }
+            else (void)hipMemcpyAsync(buf, in, total * sizeof(E), hipMemcpyDeviceToDevice, s);
+            cur_in = buf; pre = nullptr;
+        }
+        for (unsigned k = 0; k < k_first; ++k) {
             size_t h = e >> (k + 1), off = e - 2 * h;
             ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * total + 4.0 * h), k_decompose_stage<F>, dim3(nblocks(npairs)),
                          dim3(kBlock), 0, s, buf, T.np0[src] + off, T.dinv[src] + off, ilog2(h), npairs);
         }
-        for (unsigned k = le; k-- > 0;) {
+        if (le > 0 || pre || post || cur_in != buf) {
+            size_t tile = (size_t)1 << log_tile;
+            unsigned nst = le - k_first;
+            double hsum = (double)((e >> k_first) - 1);       // sum of h over the fused stages
+            double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum) + extra_alg_bytes;
+            const E* post_here = k_first == 0 ? post : nullptr;
+            ECFFT_LAUNCH(KC_FUSED_EXTEND, bytes, k_stages_lds<F>, dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                         tile * sizeof(E), s, buf, cur_in, T.np0[src], T.dinv[src], T.p0[tgt], T.p1[tgt], pre, post_here, le, k_first, log_tile);
+        }
+        for (unsigned k = k_first; k-- > 0;) {
             size_t h = e >> (k + 1), off = e - 2 * h;
             ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * total + 4.0 * h), k_recombine_stage<F>, dim3(nblocks(npairs)),
                          dim3(kBlock), 0, s, buf, T.p0[tgt] + off, T.p1[tgt] + off, ilog2(h), npairs);
         }
+        if (k_first > 0 && post)
+            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, buf, (const E*)buf, post, e - 1, total);
+    }
+    void extend_core(unsigned log_m, E* buf, size_t total, int src, hipStream_t s) const {
+        extend_core(log_m, buf, buf, total, src, nullptr, nullptr, s);
     }
 
     // FFTree::extend (src/fftree.rs:123-126) on `count` vectors of length e: uses T_{2e}; `target`
@@ -164,9 +193,7 @@ public:
         unsigned log_m = ilog2(e) + 1;
         const Tree& T = trees_[log_m];
         size_t total = e * count; int src = 1 - target;
-        hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, out, in, T.winv[src], e - 1, total);
-        extend_core(log_m, out, total, src, s);
-        hipLaunchKernelGGL(k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, out, (const E*)out, T.w[target], e - 1, total);
+        extend_core(log_m, in, out, total, src, T.winv[src], T.w[target], s);
     }
 
     // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.
@@ -182,8 +209,7 @@ public:
             E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
             // pre-scale is bookkeeping of the normalised form (0 algorithmic bytes); combine = loop C (:155-159):
             // reads u0,v0,u1,v1 (2n), x table (m), writes n
-            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(n)), dim3(kBlock), 0, s, work, src, T.winv[0], e - 1, n);
-            extend_core(l, work, n, 0, s);
+            extend_core(l, src, work, n, 0, T.winv[0], nullptr, s);
             ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * n + 2.0 * e), k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s,
                          dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), n / 2);
             src = dst;
@@ -211,8 +237,8 @@ public:
             extend_core(l, G, nh, 0, s);
             ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid1<F>, g, b, 0, s, G, H, cur, T.B1, T.NB2, le, nh);
             extend_core(l, G, nh, 1, s);
-            ECFFT_LAUNCH(KC_POINTWISE, se * (2.0 * n + 2.0 * T.e + 1.0 * n + T.e), k_scale_by_table<F>, g, b, 0, s, G, (const E*)G, T.C1, T.e - 1, nh);
-            extend_core(l, G, nh, 0, s);
+            // C1 = c_even * xinv_even: the reference's h*c and t0 = e0/a0 steps (3n + 3e algorithmic bytes), fused into the load
+            extend_core(l, G, G, nh, 0, T.C1, nullptr, s, se * (3.0 * n + 3.0 * T.e));
             ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid2<F>, g, b, 0, s, G, (const E*)H, T.D1, T.NB2, le, nh);
             extend_core(l, G, nh, 1, s);
             ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 0.5 * T.e), k_exit_split<F>, g, b, 0, s, dst, cur, (const E*)G, T.w[0], T.xie, le, nh);

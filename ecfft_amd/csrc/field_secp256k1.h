@@ -134,6 +134,12 @@ struct Secp256k1 {
         for (int j = 3; j < 8; ++j) { c += v[j]; v[j] = (uint32_t)c; c >>= 32; }
         return finish(v, (uint32_t)c);
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ECFFT_NO_ASM_MUL)
+    // hand-scheduled gfx950 instruction streams (generated by tools/gen_mulmod_asm.py)
+#include "secp256k1_mul_gfx950.inc"
+    __device__ static inline elem mul(const elem& t, const elem& x) { return mul_gfx950(t, x); }
+    __device__ static inline elem mul_add(const elem& t, const elem& x, const elem& c) { return mul_add_gfx950(t, x, c); }
+#else
     // t*x mod p
     __host__ __device__ static inline elem mul(const elem& t, const elem& x) {
         uint32_t w[16]; mul_wide(t, x, nullptr, w); return reduce_wide(w);
@@ -142,6 +148,7 @@ struct Secp256k1 {
     __host__ __device__ static inline elem mul_add(const elem& t, const elem& x, const elem& c) {
         uint32_t w[16]; mul_wide(t, x, &c, w); return reduce_wide(w);
     }
+#endif
     __host__ __device__ static inline elem sqr(const elem& a) { return mul(a, a); }
 
     __host__ __device__ static inline elem pow_u64(const elem& a, uint64_t e) {

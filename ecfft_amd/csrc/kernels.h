@@ -57,6 +57,74 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-fused butterfly stages ("row kernel").  One workgroup owns a contiguous tile of `tile` elements
+// (<= 64 KiB of LDS: 2048 secp256k1 elements / 16384 M31 elements), loads it once, runs every
+// decompose stage k in [k_first, log e) and then every recombine stage back down to k_first in LDS,
+// and stores it once — 2*(log e - k_first) stages for one HBM round trip.  Requirements: pair distance
+// of stage k_first, h = e >> (k_first+1), satisfies 2h <= tile, and tiles are tile-aligned, so the
+// table index of a butterfly is its local pair index mod h: every tile of a level reads the SAME
+// h-entry table prefix (stays L2-resident per XCD).
+//   pre  != nullptr: multiply by pre[pos mod e] while loading  (1/W normalisation, or a fused pointwise table)
+//   post != nullptr: multiply by post[pos mod e] while storing (W)
+// src and dst may be the same buffer.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlockLds = 512;
+
+template <class F>
+__global__ __launch_bounds__(kBlockLds) void k_stages_lds(typename F::elem* dst, const typename F::elem* src,
+                                                           const typename F::elem* __restrict__ np0,
+                                                           const typename F::elem* __restrict__ dinv,
+                                                           const typename F::elem* __restrict__ p0,
+                                                           const typename F::elem* __restrict__ p1,
+                                                           const typename F::elem* __restrict__ pre,
+                                                           const typename F::elem* __restrict__ post,
+                                                           uint32_t log_e, uint32_t k_first, uint32_t log_tile) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    E* tile = reinterpret_cast<E*>(ecfft_smem);
+    const uint32_t T = 1u << log_tile, tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x << log_tile;
+    const size_t emask = ((size_t)1 << log_e) - 1;
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        E v = src[base + j];
+        if (pre) v = F::mul(pre[(base + j) & emask], v);
+        tile[j] = v;
+    }
+    __syncthreads();
+    const uint32_t npairs = T >> 1;
+    for (uint32_t k = k_first; k < log_e; ++k) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const E* tn = np0 + (((size_t)1 << log_e) - 2 * (size_t)h);
+        const E* td = dinv + (((size_t)1 << log_e) - 2 * (size_t)h);
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+            E a = tile[idx], b = tile[idx + h];
+            E q1 = F::mul(td[i], F::sub(b, a));
+            E q0 = F::mul_add(tn[i], q1, a);
+            tile[idx] = q0; tile[idx + h] = q1;
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = log_e; k-- > k_first;) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const E* t0 = p0 + (((size_t)1 << log_e) - 2 * (size_t)h);
+        const E* t1 = p1 + (((size_t)1 << log_e) - 2 * (size_t)h);
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+            E a = tile[idx], b = tile[idx + h];
+            tile[idx] = F::mul_add(t0[i], b, a);
+            tile[idx + h] = F::mul_add(t1[i], b, a);
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        E v = tile[j];
+        if (post) v = F::mul(post[(base + j) & emask], v);
+        dst[base + j] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pointwise kernels of ENTER (src/fftree.rs:143-161) — level m, e = m/2, n/m blocks
 // ---------------------------------------------------------------------------------------------
 // work[j] = src[j] * winv0[j mod e]
