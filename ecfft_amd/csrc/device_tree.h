@@ -41,9 +41,9 @@ static inline void foreach_n(hipStream_t s, size_t n, Fn fn) {
 // reads and writes its operand once and reads its stage tables once; each pointwise step reads its
 // operands and tables and writes its result once.
 // ---------------------------------------------------------------------------------------------
-enum KernelClass { KC_DECOMPOSE = 0, KC_RECOMBINE, KC_POINTWISE, KC_FUSED_EXTEND, KC_FUSED_ENTER, KC_FUSED_EXIT, KC_COUNT };
+enum KernelClass { KC_DECOMPOSE = 0, KC_RECOMBINE, KC_POINTWISE, KC_ROW, KC_COL, KC_FUSED_ENTER, KC_FUSED_EXIT, KC_COUNT };
 static const char* const kKernelClassName[KC_COUNT] = {"k_decompose_stage", "k_recombine_stage", "pointwise",
-                                                       "k_extend_fused", "k_enter_fused", "k_exit_fused"};
+                                                       "k_stages_lds", "k_stages_col", "k_enter_low", "k_exit_low"};
 
 class Profiler {
 public:
@@ -141,50 +141,69 @@ public:
     // EXTEND core: all 2*log(e) normalised stages, in place, on `total` elements = count vectors
     // of length e = m/2 laid end to end.  src = parity of the moiety the data lives on.
     // ------------------------------------------------------------------------------------------
-    // pre/post: optional per-position tables (indexed pos mod e) multiplied in on the way in / out.
-    // in may differ from buf (out-of-place first touch).  Stages whose pair distance does not fit the
-    // LDS tile stream through HBM one launch per stage; the rest run fused in k_stages_lds.
-    static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? 11 : 14;     // 64 KiB of LDS
-    void extend_core(unsigned log_m, const E* in, E* buf, size_t total, int src, const E* pre, const E* post, hipStream_t s,
-                     double extra_alg_bytes = 0.0) const {
+    // ------------------------------------------------------------------------------------------
+    // EXTEND core: all 2*log(e) normalised stages on `total` elements = count vectors of length
+    // e = m/2 laid end to end, as a chain of fused passes:
+    //     [column passes: top decompose stages, <= 4 per pass] -> row pass (every stage with
+    //     2h <= tile, decompose then recombine) -> [column passes: top recombine stages].
+    // `io` describes where the first pass loads from (with an optional fused pointwise op) and what
+    // the last pass does with its result; intermediate passes run in place on `buf`.
+    // srcpar = parity of the moiety the data lives on.
+    // ------------------------------------------------------------------------------------------
+#ifndef ECFFT_LOG_TILE_BYTES
+#define ECFFT_LOG_TILE_BYTES 15
+#endif
+    static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
+    static constexpr unsigned kColStages = 4;
+    void extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
+                     double extra_first = 0.0, double extra_last = 0.0) const {
         const Tree& T = trees_[log_m];
         size_t e = T.e; unsigned le = ilog2(e);
-        int tgt = 1 - src;
-        size_t npairs = total / 2;
+        int tgt = 1 - srcpar;
         unsigned tz = (unsigned)__builtin_ctzll((unsigned long long)total);   // tiles must divide count*e
         unsigned log_tile = tz < kLogTileMax ? tz : kLogTileMax;
-        // first fused stage: 2h <= tile  <=>  le - k <= log_tile
-        unsigned k_first = le > log_tile ? le - log_tile : 0;
-        const E* cur_in = in;
-        if (k_first > 0 && (pre || in != buf)) {
-            if (pre) { ECFFT_LAUNCH(KC_POINTWISE, extra_alg_bytes, k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, buf, in, pre, e - 1, total); extra_alg_bytes = 0.0; }
-            else (void)hipMemcpyAsync(buf, in, total * sizeof(E), hipMemcpyDeviceToDevice, s);
-            cur_in = buf; pre = nullptr;
+        unsigned k_first = le > log_tile ? le - log_tile : 0;                 // first stage with 2h <= tile
+        // pass list: (kind, ka, kb)
+        struct Pass { int kind; unsigned ka, kb; };                           // kind 0 col-decompose, 1 row, 2 col-recombine
+        Pass passes[2 * 8 + 1]; int np = 0;
+        for (unsigned k = 0; k < k_first; k += kColStages) { unsigned kb = k + kColStages - 1 < k_first - 1 ? k + kColStages - 1 : k_first - 1; passes[np++] = {0, k, kb}; }
+        int nd = np;
+        passes[np++] = {1, k_first, le};
+        for (int g = nd - 1; g >= 0; --g) passes[np++] = {2, passes[g].ka, passes[g].kb};
+        const E* plain_src = buf;
+        for (int pi = 0; pi < np; ++pi) {
+            IoDesc<E> d;
+            bool first = pi == 0, last = pi == np - 1;
+            // load side
+            if (first) { d = io; } else { d = IoDesc<E>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
+            // store side
+            if (last) { d.dst = io.dst; d.st_mode = io.st_mode; d.st_a = io.st_a; d.st_b = io.st_b; d.aux = io.aux; d.aux_stride = io.aux_stride; d.aux_off = io.aux_off; d.aux_out = io.aux_out; }
+            else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
+            double extra = (first ? extra_first : 0.0) + (last ? extra_last : 0.0);
+            const Pass& P = passes[pi];
+            if (P.kind == 1) {
+                unsigned nst = le - k_first;
+                double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
+                double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum) + extra;
+                ECFFT_LAUNCH(KC_ROW, bytes, k_stages_lds<F>, dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                             ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], le, k_first, log_tile);
+            } else {
+                unsigned R = P.kb - P.ka + 1, log_c = log_tile - R;
+                double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
+                double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum) + extra;
+                if (P.kind == 0)
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
+                else
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
+            }
         }
-        for (unsigned k = 0; k < k_first; ++k) {
-            size_t h = e >> (k + 1), off = e - 2 * h;
-            ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * total + 4.0 * h), k_decompose_stage<F>, dim3(nblocks(npairs)),
-                         dim3(kBlock), 0, s, buf, T.np0[src] + off, T.dinv[src] + off, ilog2(h), npairs);
-        }
-        if (le > 0 || pre || post || cur_in != buf) {
-            size_t tile = (size_t)1 << log_tile;
-            unsigned nst = le - k_first;
-            double hsum = (double)((e >> k_first) - 1);       // sum of h over the fused stages
-            double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum) + extra_alg_bytes;
-            const E* post_here = k_first == 0 ? post : nullptr;
-            ECFFT_LAUNCH(KC_FUSED_EXTEND, bytes, k_stages_lds<F>, dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
-                         tile * sizeof(E), s, buf, cur_in, T.np0[src], T.dinv[src], T.p0[tgt], T.p1[tgt], pre, post_here, le, k_first, log_tile);
-        }
-        for (unsigned k = k_first; k-- > 0;) {
-            size_t h = e >> (k + 1), off = e - 2 * h;
-            ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * total + 4.0 * h), k_recombine_stage<F>, dim3(nblocks(npairs)),
-                         dim3(kBlock), 0, s, buf, T.p0[tgt] + off, T.p1[tgt] + off, ilog2(h), npairs);
-        }
-        if (k_first > 0 && post)
-            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(total)), dim3(kBlock), 0, s, buf, (const E*)buf, post, e - 1, total);
     }
-    void extend_core(unsigned log_m, E* buf, size_t total, int src, hipStream_t s) const {
-        extend_core(log_m, buf, buf, total, src, nullptr, nullptr, s);
+    static IoDesc<E> io_plain(const E* src, E* dst) {
+        IoDesc<E> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;
+        d.dst = dst; d.st_mode = ST_PLAIN; d.st_a = d.st_b = d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr;
+        return d;
     }
 
     // FFTree::extend (src/fftree.rs:123-126) on `count` vectors of length e: uses T_{2e}; `target`
@@ -193,7 +212,10 @@ public:
         unsigned log_m = ilog2(e) + 1;
         const Tree& T = trees_[log_m];
         size_t total = e * count; int src = 1 - target;
-        extend_core(log_m, in, out, total, src, T.winv[src], T.w[target], s);
+        IoDesc<E> io = io_plain(in, out);
+        io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[src];
+        io.st_mode = ST_SCALE; io.st_a = T.w[target];
+        extend_core(log_m, io, out, total, src, s);
     }
 
     // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.
@@ -209,7 +231,7 @@ public:
             E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
             // pre-scale is bookkeeping of the normalised form (0 algorithmic bytes); combine = loop C (:155-159):
             // reads u0,v0,u1,v1 (2n), x table (m), writes n
-            extend_core(l, src, work, n, 0, T.winv[0], nullptr, s);
+            { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, n, 0, s); }
             ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * n + 2.0 * e), k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s,
                          dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), n / 2);
             src = dst;
@@ -229,19 +251,28 @@ public:
             unsigned le = ilog2(T.e);
             E* dst = (l == 1 && out != in) ? out : (cur == bufA ? bufB : bufA);
             dim3 g(nblocks(nh)), b(kBlock);
-            // algorithmic bytes of the pointwise steps per level (8.5 n + 8.5 m/2 ... split per step):
-            //   t0 = e0*a0inv: r n/2 + tbl e + w n/2 ; h1: r n (e1,g1) + tbl 2e + w n/2 ; hc = h*c: r n + tbl m + w n ;
-            //   second redc the same two steps ; split v0 = (e0-u0)*xinv: r n + tbl e/2.. (SURVEY totals 8.5 n + 8.5 e per level)
-            double se = sizeof(E);
-            ECFFT_LAUNCH(KC_POINTWISE, se * (1.0 * n + T.e), k_exit_pre1<F>, g, b, 0, s, G, cur, T.A1, le, nh);
-            extend_core(l, G, nh, 0, s);
-            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid1<F>, g, b, 0, s, G, H, cur, T.B1, T.NB2, le, nh);
-            extend_core(l, G, nh, 1, s);
-            // C1 = c_even * xinv_even: the reference's h*c and t0 = e0/a0 steps (3n + 3e algorithmic bytes), fused into the load
-            extend_core(l, G, G, nh, 0, T.C1, nullptr, s, se * (3.0 * n + 3.0 * T.e));
-            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 2.0 * T.e), k_exit_mid2<F>, g, b, 0, s, G, (const E*)H, T.D1, T.NB2, le, nh);
-            extend_core(l, G, nh, 1, s);
-            ECFFT_LAUNCH(KC_POINTWISE, se * (1.5 * n + 0.5 * T.e), k_exit_split<F>, g, b, 0, s, dst, cur, (const E*)G, T.w[0], T.xie, le, nh);
+            // The reference's pointwise steps of this level (8.5 n + 8.5 e algorithmic element moves)
+            // are all folded into the first load / last store of the four EXTEND cores:
+            //   core 1  load  t0 = e0 * (xinv_even / W0)                    [t0 = e0/a0        : n + e   ]
+            //           store h1~ = e1 * (zinv/W1) - g1~ * (x_odd zinv)      [h1                : 1.5n + 2e], kept in H
+            //   core 2  h1~ -> h0~ (S1 -> S0)
+            //   core 3  load  t0' = h0~ * (c_even xinv_even)                 [h*c and t0'       : 3n + 3e ]
+            //           store h1'~ = H * (c_odd zinv) - g1'~ * (x_odd zinv)  [h1'               : 1.5n + 2e]
+            //   core 4  store u0 = W0 q0~ ; v0 = (e0 - u0) * xinv_even       [exit split        : 1.5n + 0.5e]
+            double se = sizeof(E), ee = (double)T.e;
+            IoDesc<E> io1 = io_plain(cur, G);
+            io1.src_stride = 2; io1.src_off = 0; io1.ld_mode = LD_SCALE; io1.ld_tbl = T.A1;
+            io1.st_mode = ST_AXPBY; io1.st_a = T.NB2; io1.st_b = T.B1; io1.aux = cur; io1.aux_stride = 2; io1.aux_off = 1; io1.aux_out = H;
+            extend_core(l, io1, G, nh, 0, s, se * (1.0 * n + ee), se * (1.5 * n + 2.0 * ee));
+            extend_core(l, io_plain(G, G), G, nh, 1, s);
+            IoDesc<E> io3 = io_plain(G, G);
+            io3.ld_mode = LD_SCALE; io3.ld_tbl = T.C1;
+            io3.st_mode = ST_AXPBY; io3.st_a = T.NB2; io3.st_b = T.D1; io3.aux = H; io3.aux_stride = 1; io3.aux_off = 0; io3.aux_out = nullptr;
+            extend_core(l, io3, G, nh, 0, s, se * (3.0 * n + 3.0 * ee), se * (1.5 * n + 2.0 * ee));
+            IoDesc<E> io4 = io_plain(G, dst);
+            io4.st_mode = ST_EXIT_SPLIT; io4.st_a = T.w[0]; io4.st_b = T.xie; io4.aux = cur; io4.aux_stride = 2; io4.aux_off = 0;
+            extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee));
+            (void)g; (void)b; (void)le;
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);

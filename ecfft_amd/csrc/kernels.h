@@ -57,45 +57,88 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-fused butterfly stages ("row kernel").  One workgroup owns a contiguous tile of `tile` elements
-// (<= 64 KiB of LDS: 2048 secp256k1 elements / 16384 M31 elements), loads it once, runs every
-// decompose stage k in [k_first, log e) and then every recombine stage back down to k_first in LDS,
-// and stores it once — 2*(log e - k_first) stages for one HBM round trip.  Requirements: pair distance
-// of stage k_first, h = e >> (k_first+1), satisfies 2h <= tile, and tiles are tile-aligned, so the
-// table index of a butterfly is its local pair index mod h: every tile of a level reads the SAME
-// h-entry table prefix (stays L2-resident per XCD).
-//   pre  != nullptr: multiply by pre[pos mod e] while loading  (1/W normalisation, or a fused pointwise table)
-//   post != nullptr: multiply by post[pos mod e] while storing (W)
-// src and dst may be the same buffer.
+// Fused load / store operators.  Every pointwise step of ENTER / EXIT that sits between two EXTEND
+// cores is folded into the first load or the last store of the neighbouring fused-stage kernel, so it
+// costs no HBM pass of its own.  `pos` is the element's position in the work buffer (count vectors of
+// length e laid end to end), i = pos mod e.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBlockLds = 512;
+enum { LD_PLAIN = 0, LD_SCALE = 1 };
+enum { ST_PLAIN = 0, ST_SCALE = 1, ST_AXPBY = 2, ST_EXIT_SPLIT = 3 };
+
+template <class E>
+struct IoDesc {
+    // load:  x = [ld_tbl[i] *] src[src_stride*pos + src_off]
+    const E* src; uint32_t src_stride, src_off; int ld_mode; const E* ld_tbl;
+    // store: ST_PLAIN  dst[pos] = x
+    //        ST_SCALE  dst[pos] = st_a[i]*x
+    //        ST_AXPBY  r = st_a[i]*x + st_b[i]*aux[aux_stride*pos + aux_off]; dst[pos] = r; aux_out[pos] = r (if set)
+    //        ST_EXIT_SPLIT  u0 = st_a[i]*x; v0 = st_b[i]*(aux[2*pos] - u0); dst[b*2e + i] = u0; dst[b*2e + e + i] = v0  (b = pos / e)
+    E* dst; int st_mode; const E* st_a; const E* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out;
+};
 
 template <class F>
-__global__ __launch_bounds__(kBlockLds) void k_stages_lds(typename F::elem* dst, const typename F::elem* src,
+__device__ __forceinline__ typename F::elem io_load(const IoDesc<typename F::elem>& io, size_t pos, size_t emask) {
+    typename F::elem v = io.src[(size_t)io.src_stride * pos + io.src_off];
+    if (io.ld_mode == LD_SCALE) v = F::mul(io.ld_tbl[pos & emask], v);
+    return v;
+}
+template <class F>
+__device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, size_t pos, uint32_t log_e, const typename F::elem& x) {
+    using E = typename F::elem;
+    const size_t emask = ((size_t)1 << log_e) - 1, i = pos & emask;
+    switch (io.st_mode) {
+        case ST_PLAIN: io.dst[pos] = x; break;
+        case ST_SCALE: io.dst[pos] = F::mul(io.st_a[i], x); break;
+        case ST_AXPBY: {
+            E r = F::mul_add(io.st_a[i], x, F::mul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+            io.dst[pos] = r;
+            if (io.aux_out) io.aux_out[pos] = r;
+            break;
+        }
+        default: {  // ST_EXIT_SPLIT
+            E u0 = F::mul(io.st_a[i], x);
+            E v0 = F::mul(io.st_b[i], F::sub(io.aux[2 * pos], u0));
+            size_t base = (pos >> log_e) << (log_e + 1);
+            io.dst[base + i] = u0;
+            io.dst[base + ((size_t)1 << log_e) + i] = v0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-fused butterfly stages, "row kernel".  One workgroup owns a contiguous tile of 2^log_tile
+// elements (<= 64 KiB of LDS: 2048 secp256k1 / 16384 M31 elements), loads it once, runs every
+// decompose stage k in [k_first, log e) and then every recombine stage back down to k_first in LDS,
+// and stores it once: 2*(log e - k_first) stages for one HBM round trip.  Stage k_first has pair
+// distance h = e >> (k_first+1) with 2h <= tile and tiles are tile-aligned, so a butterfly's table
+// index is its local pair index mod h: every tile of a level reads the SAME h-entry table prefix
+// (L2-resident per XCD).
+// ---------------------------------------------------------------------------------------------
+#ifndef ECFFT_BLOCK_LDS
+#define ECFFT_BLOCK_LDS 512
+#endif
+constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS-fused kernels
+
+template <class F>
+__global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ np0,
                                                            const typename F::elem* __restrict__ dinv,
                                                            const typename F::elem* __restrict__ p0,
                                                            const typename F::elem* __restrict__ p1,
-                                                           const typename F::elem* __restrict__ pre,
-                                                           const typename F::elem* __restrict__ post,
                                                            uint32_t log_e, uint32_t k_first, uint32_t log_tile) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
     const uint32_t T = 1u << log_tile, tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x << log_tile;
-    const size_t emask = ((size_t)1 << log_e) - 1;
-    for (uint32_t j = tid; j < T; j += kBlockLds) {
-        E v = src[base + j];
-        if (pre) v = F::mul(pre[(base + j) & emask], v);
-        tile[j] = v;
-    }
+    const size_t e = (size_t)1 << log_e, emask = e - 1;
+    for (uint32_t j = tid; j < T; j += kBlockLds) tile[j] = io_load<F>(io, base + j, emask);
     __syncthreads();
     const uint32_t npairs = T >> 1;
     for (uint32_t k = k_first; k < log_e; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        const E* tn = np0 + (((size_t)1 << log_e) - 2 * (size_t)h);
-        const E* td = dinv + (((size_t)1 << log_e) - 2 * (size_t)h);
+        const E* tn = np0 + (e - 2 * (size_t)h);
+        const E* td = dinv + (e - 2 * (size_t)h);
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
             E a = tile[idx], b = tile[idx + h];
@@ -107,8 +150,8 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(typename F::elem* dst,
     }
     for (uint32_t k = log_e; k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        const E* t0 = p0 + (((size_t)1 << log_e) - 2 * (size_t)h);
-        const E* t1 = p1 + (((size_t)1 << log_e) - 2 * (size_t)h);
+        const E* t0 = p0 + (e - 2 * (size_t)h);
+        const E* t1 = p1 + (e - 2 * (size_t)h);
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
             E a = tile[idx], b = tile[idx + h];
@@ -117,10 +160,66 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(typename F::elem* dst,
         }
         __syncthreads();
     }
+    for (uint32_t j = tid; j < T; j += kBlockLds) io_store<F>(io, base + j, log_e, tile[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-fused butterfly stages, "column kernel": the R = kb-ka+1 consecutive stages ka..kb whose pair
+// distances (h_ka = hs*2^(R-1) ... h_kb = hs) are too large for a contiguous tile.  A workgroup
+// gathers 2^R rows spaced hs apart, 2^log_c contiguous elements each (>= 4 KiB per row for R <= 4 on
+// secp256k1: fully coalesced), runs the R stages in LDS and scatters the rows back.  DECOMPOSE runs
+// ka -> kb (large distance first), RECOMBINE kb -> ka.  Table index of the pair (row r, column c) at
+// stage k: (r mod d)*hs + c_global with d = 2^(kb-k).
+// ---------------------------------------------------------------------------------------------
+template <class F, bool DECOMPOSE>
+__global__ __launch_bounds__(kBlockLds) void k_stages_col(IoDesc<typename F::elem> io,
+                                                           const typename F::elem* __restrict__ ta,   // np0 | p0
+                                                           const typename F::elem* __restrict__ tb,   // dinv | p1
+                                                           uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    E* tile = reinterpret_cast<E*>(ecfft_smem);
+    const uint32_t R = kb - ka + 1, tid = threadIdx.x;
+    const uint32_t C = 1u << log_c, T = C << R;
+    const size_t e = (size_t)1 << log_e, emask = e - 1;
+    const uint32_t log_hs = log_e - kb - 1;
+    const size_t hs = (size_t)1 << log_hs;
+    const uint32_t chunks_log = log_hs - log_c;                      // column chunks per 2h_ka block
+    const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+    const size_t B = (blk << (log_hs + R)) + (chunk << log_c);       // position of (row 0, col 0)
+    const size_t c0 = (chunk << log_c);                              // column offset inside the hs-block
     for (uint32_t j = tid; j < T; j += kBlockLds) {
-        E v = tile[j];
-        if (post) v = F::mul(post[(base + j) & emask], v);
-        dst[base + j] = v;
+        uint32_t r = j >> log_c, cc = j & (C - 1);
+        tile[j] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
+    }
+    __syncthreads();
+    const uint32_t npairs = T >> 1;
+    for (uint32_t st = 0; st < R; ++st) {
+        const uint32_t k = DECOMPOSE ? ka + st : kb - st;
+        const uint32_t s = kb - k, d = 1u << s;                      // row distance of the pair
+        const size_t h = hs << s;
+        const E* pa = ta + (e - 2 * h);
+        const E* pb = tb + (e - 2 * h);
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            uint32_t cc = g & (C - 1), pr = g >> log_c;
+            uint32_t r = ((pr >> s) << (s + 1)) | (pr & (d - 1));
+            size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
+            uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+            E a = tile[lo], b = tile[hi];
+            if (DECOMPOSE) {
+                E q1 = F::mul(pb[i], F::sub(b, a));
+                E q0 = F::mul_add(pa[i], q1, a);
+                tile[lo] = q0; tile[hi] = q1;
+            } else {
+                tile[lo] = F::mul_add(pa[i], b, a);
+                tile[hi] = F::mul_add(pb[i], b, a);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        uint32_t r = j >> log_c, cc = j & (C - 1);
+        io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[j]);
     }
 }
 

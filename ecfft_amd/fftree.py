@@ -52,7 +52,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        path = os.path.join(_DIR, "libecfft_hip.so")
+        path = os.environ.get("ECFFT_LIB") or os.path.join(_DIR, "libecfft_hip.so")   # ECFFT_LIB: A/B builds for tuning
         if not os.path.exists(path):
             _build.build()
         L = ctypes.CDLL(path)
