@@ -1,0 +1,91 @@
+// ecfft_fftree.hpp — C++ host-side mirror of the reference's `FFTree<F>` / `FftreeField` surface
+// (/root/reference/src/lib.rs:14-16, src/fftree.rs:17-38, 42, 123, 164, 227, 489) over the C ABI of
+// ecfft_hip.h.  Header-only; link with libecfft_hip.so.  Same names, argument meaning and error
+// behaviour: where the Rust code panics this throws (std::invalid_argument for non powers of two,
+// std::length_error("FFTree is too small")), `build_fftree` returns std::nullopt where Rust returns None.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <vector>
+#include "ecfft_hip.h"
+
+namespace ecfft_host {
+
+enum class Moiety { S0 = ECFFT_S0, S1 = ECFFT_S1 };                       // src/fftree.rs:17-21
+
+struct Secp256k1Fp { static constexpr int id = ECFFT_FIELD_SECP256K1; using Elem = std::array<uint64_t, 4>; };  // Montgomery limbs
+struct M31Fp { static constexpr int id = ECFFT_FIELD_M31; using Elem = uint32_t; };
+
+inline void check(int rc) {
+    switch (rc) {
+        case ECFFT_OK: return;
+        case ECFFT_ERR_NOT_POW2: throw std::invalid_argument("length must be a power of two");
+        case ECFFT_ERR_TREE_TOO_SMALL: throw std::length_error("FFTree is too small");
+        case ECFFT_ERR_HIP: throw std::runtime_error("ecfft: HIP failure (no usable device?) - there is no CPU fallback");
+        default: throw std::runtime_error("ecfft: error " + std::to_string(rc));
+    }
+}
+
+template <class F>
+class FFTree {
+public:
+    using Elem = typename F::Elem;
+    FFTree(const FFTree&) = delete;
+    FFTree& operator=(const FFTree&) = delete;
+    FFTree(FFTree&& o) noexcept : ctx_(o.ctx_) { o.ctx_ = nullptr; }
+    ~FFTree() { if (ctx_) ecfft_ctx_destroy(ctx_); }
+
+    // FftreeField::build_fftree (src/lib.rs:14-16)
+    static std::optional<FFTree> build_fftree(size_t n, int device = 0) {
+        ecfft_ctx* c = nullptr;
+        int rc = ecfft_build_fftree(F::id, n, device, &c);
+        if (rc == ECFFT_ERR_TREE_TOO_LARGE) return std::nullopt;
+        check(rc);
+        return FFTree(c);
+    }
+    // FFTree::new (src/fftree.rs:42-70): maps as 3 numerator + 3 denominator coefficients each
+    static FFTree from_leaves(const std::vector<Elem>& leaves, const std::vector<Elem>& num3, const std::vector<Elem>& den3, int device = 0) {
+        ecfft_ctx* c = nullptr;
+        check(ecfft_fftree_new(F::id, leaves.data(), leaves.size(), num3.data(), den3.data(), device, &c));
+        return FFTree(c);
+    }
+    size_t size() const { return ecfft_tree_size(ctx_); }
+
+    std::vector<Elem> enter(const std::vector<Elem>& coeffs) const {            // src/fftree.rs:164-167
+        std::vector<Elem> out(coeffs.size());
+        check(ecfft_enter(ctx_, coeffs.data(), out.data(), coeffs.size(), ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    std::vector<Elem> exit(const std::vector<Elem>& evals) const {              // src/fftree.rs:227-230
+        std::vector<Elem> out(evals.size());
+        check(ecfft_exit(ctx_, evals.data(), out.data(), evals.size(), ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    std::vector<Elem> extend(const std::vector<Elem>& evals, Moiety moiety) const {   // src/fftree.rs:123-126
+        std::vector<Elem> out(evals.size());
+        check(ecfft_extend(ctx_, evals.data(), out.data(), evals.size(), (int)moiety, 1, ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    // device-resident variants (pointers into HBM, caller's stream)
+    void enter_device(const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter(ctx_, coeffs, evals, n, ECFFT_MEM_DEVICE, stream)); }
+    void exit_device(const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit(ctx_, evals, coeffs, n, ECFFT_MEM_DEVICE, stream)); }
+    void extend_device(const Elem* in, Elem* out, size_t e, Moiety m, size_t count, void* stream) const { check(ecfft_extend(ctx_, in, out, e, (int)m, count, ECFFT_MEM_DEVICE, stream)); }
+
+    // pub tables of the subtree with m leaves (src/fftree.rs:24-38, 489-496)
+    std::vector<Elem> table(int which, size_t m) const {
+        size_t cnt = 0;
+        check(ecfft_tree_table(ctx_, m, which, nullptr, 0, &cnt));
+        std::vector<Elem> out(cnt);
+        check(ecfft_tree_table(ctx_, m, which, out.data(), cnt, &cnt));
+        return out;
+    }
+    ecfft_ctx* raw() const { return ctx_; }
+
+private:
+    explicit FFTree(ecfft_ctx* c) : ctx_(c) {}
+    ecfft_ctx* ctx_;
+};
+
+}  // namespace ecfft_host

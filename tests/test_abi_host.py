@@ -1,0 +1,67 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads, exports every symbol that
+include/ecfft_hip.h declares, reports the reference's size limits and argument errors without a GPU,
+fails loudly (no CPU fallback) when asked to compute without one, and its host-side construction of
+the FFTree point sets (leaves, isogeny x-maps, inner layers) matches the oracle and the golden vectors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, std_to_field
+
+
+@pytest.fixture(scope="module")
+def prod():
+    import ecfft_amd
+    ecfft_amd.build.build()
+    return ecfft_amd
+
+
+def test_library_exports_every_declared_symbol(prod):
+    header = open(os.path.join(ROOT, "include", "ecfft_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ecfft_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 12
+    L = prod.lib()
+    for sym in declared:
+        assert hasattr(L, sym), f"libecfft_hip.so does not export {sym}"
+    assert sorted(prod.fftree.EXPORTS) == declared
+
+
+def test_elem_sizes_and_limits_without_gpu(prod):
+    L = prod.lib()
+    assert L.ecfft_elem_size(0) == 32 and L.ecfft_elem_size(1) == 4 and L.ecfft_elem_size(7) == 0
+    # build_fftree -> None beyond the curve's 2-adicity (src/lib.rs:62-64, src/ec.rs:513-515): decided before touching a device
+    assert prod.secp256k1.build_fftree(1 << 36) is None
+    assert prod.m31.build_fftree(1 << 29) is None
+    with pytest.raises(AssertionError):          # assert!(n.is_power_of_two()), src/lib.rs:41
+        prod.secp256k1.build_fftree(48)
+
+
+def test_no_cpu_fallback(prod):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(prod.EcfftError):
+        prod.secp256k1.build_fftree(64)
+
+
+@pytest.mark.parametrize("field,n", [("secp256k1", 4), ("secp256k1", 64), ("secp256k1", 4096), ("m31", 4), ("m31", 64), ("m31", 4096)])
+def test_host_point_sets_match_oracle_and_golden(prod, oracle_tree, oracle_mod, field, n):
+    F, ot = oracle_tree(field, n)
+    f, num, den = prod.FIELDS[field].build_points(n)
+    g = load_golden(field, n)
+    assert np.array_equal(f[n:], std_to_field(F, g["leaves"]))            # x(coset_offset + i*G)
+    assert np.array_equal(f[1:], ot.table(oracle_mod.T_F)[1:])            # every inner layer
+    for k in range(n.bit_length() - 1):
+        onum, oden = ot.rational_map(k)
+        assert np.array_equal(num[3 * k:3 * k + 3], onum) and np.array_equal(den[3 * k:3 * k + 3], oden)
+
+
+def test_host_point_sets_large(prod, oracle_mod):
+    """2^16 leaves through the batched-inversion construction == sequential affine additions of the oracle"""
+    F = oracle_mod.field("m31")
+    ot = F.build_fftree(1 << 16)
+    f, _, _ = prod.m31.build_points(1 << 16)
+    assert np.array_equal(f[1:], ot.table(oracle_mod.T_F)[1:])
