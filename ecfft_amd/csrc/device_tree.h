@@ -156,17 +156,19 @@ public:
     static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
     static constexpr unsigned kColStages = 4;
     void extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
-                     double extra_first = 0.0, double extra_last = 0.0) const {
+                     double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0) const {
+        // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
         const Tree& T = trees_[log_m];
         size_t e = T.e; unsigned le = ilog2(e);
         int tgt = 1 - srcpar;
         unsigned tz = (unsigned)__builtin_ctzll((unsigned long long)total);   // tiles must divide count*e
         unsigned log_tile = tz < kLogTileMax ? tz : kLogTileMax;
         unsigned k_first = le > log_tile ? le - log_tile : 0;                 // first stage with 2h <= tile
+        if (k_first < k_begin) k_first = k_begin;
         // pass list: (kind, ka, kb)
         struct Pass { int kind; unsigned ka, kb; };                           // kind 0 col-decompose, 1 row, 2 col-recombine
         Pass passes[2 * 8 + 1]; int np = 0;
-        for (unsigned k = 0; k < k_first; k += kColStages) { unsigned kb = k + kColStages - 1 < k_first - 1 ? k + kColStages - 1 : k_first - 1; passes[np++] = {0, k, kb}; }
+        for (unsigned k = k_begin; k < k_first; k += kColStages) { unsigned kb = k + kColStages - 1 < k_first - 1 ? k + kColStages - 1 : k_first - 1; passes[np++] = {0, k, kb}; }
         int nd = np;
         passes[np++] = {1, k_first, le};
         for (int g = nd - 1; g >= 0; --g) passes[np++] = {2, passes[g].ka, passes[g].kb};
@@ -216,6 +218,43 @@ public:
         io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[src];
         io.st_mode = ST_SCALE; io.st_a = T.w[target];
         extend_core(log_m, io, out, total, src, s);
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // Building blocks of ONE EXTEND split over P = 2^log_p GPUs.  The vector of
+    // length e lives on T_{2e}; `target` is the target moiety.
+    //   cyclic shard: local element j' <-> global position j'*P + rank, local length e/P; stage k < log
+    //     e - log_p pairs (j', j' + h_k/P) and reads table entry (j' mod h_k/P)*P + rank.
+    //   block shard: local element j' <-> global position rank*e/P + j'; stages k >= log_p are local and
+    //     use exactly the single-GPU kernels (table index = local pair index mod h).
+    // ------------------------------------------------------------------------------------------
+    // cyclic shard, decompose side: multiply by 1/W_src, then stages 0 .. log_p-1
+    // cyclic shard, recombine side: stages log_p-1 .. 0, then multiply by W_tgt
+    void extend_top_cyclic(E* buf, size_t e, int target, unsigned log_p, unsigned rank, bool recombine, hipStream_t s) const {
+        unsigned log_m = ilog2(e) + 1;
+        const Tree& T = trees_[log_m];
+        int src = 1 - target;
+        size_t P = (size_t)1 << log_p, el = e >> log_p, npairs = el / 2;
+        if (!recombine) {
+            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(el)), dim3(kBlock), 0, s, buf, (const E*)buf, T.winv[src], el - 1, el, (uint32_t)P, rank);
+            for (unsigned k = 0; k < log_p; ++k) {
+                size_t h = e >> (k + 1), off = e - 2 * h;
+                ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * el + 4.0 * (h >> log_p)), k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                             buf, T.np0[src] + off, T.dinv[src] + off, ilog2(h >> log_p), npairs, (uint32_t)P, rank);
+            }
+        } else {
+            for (unsigned k = log_p; k-- > 0;) {
+                size_t h = e >> (k + 1), off = e - 2 * h;
+                ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * el + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                             buf, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, rank);
+            }
+            ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(el)), dim3(kBlock), 0, s, buf, (const E*)buf, T.w[target], el - 1, el, (uint32_t)P, rank);
+        }
+    }
+    // block shard: decompose stages k >= log_p then recombine stages back down to log_p, fused passes, in place
+    void extend_local_block(E* buf, size_t e, int target, unsigned log_p, hipStream_t s) const {
+        unsigned log_m = ilog2(e) + 1;
+        extend_core(log_m, io_plain(buf, buf), buf, e >> log_p, 1 - target, s, 0.0, 0.0, log_p);
     }
 
     // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.

@@ -135,6 +135,36 @@ int table_of(const DeviceChain<F>& ch, size_t m, int which, void* host_out, size
 
 }  // namespace
 
+namespace {
+template <class F>
+int run_shard(ecfft_ctx* c, DeviceChain<F>& ch, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int which, int mem, void* stream) {
+    using E = typename F::elem;
+    if (!buf) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(e)) return ECFFT_ERR_NOT_POW2;
+    if (2 * e > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
+    if (moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
+    if (((size_t)2 << log_p) > e || rank >= (1u << log_p)) return ECFFT_ERR_BAD_ARG;   // need >= 2 elements per rank
+    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> guard(ch.lock());
+    size_t bytes = (e >> log_p) * sizeof(E);
+    E* d = (E*)buf;
+    if (mem == ECFFT_MEM_HOST) {
+        if (!ensure_stage(c, bytes)) return ECFFT_ERR_HIP;
+        d = (E*)c->stage;
+        if (hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP;
+    } else if (mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    if (which == 2) ch.extend_local_block(d, e, moiety, log_p, s);
+    else ch.extend_top_cyclic(d, e, moiety, log_p, rank, which == 1, s);
+    if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
+    if (mem == ECFFT_MEM_HOST) {
+        if (hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
+        if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
+    }
+    return ECFFT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
@@ -265,6 +295,17 @@ int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXTEND, in, out, e, count, moiety, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_EXTEND, in, out, e, count, moiety, mem, stream);
+}
+
+int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int recombine, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream)
+                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream);
+}
+int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, 0, 2, mem, stream)
+                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, 0, 2, mem, stream);
 }
 
 int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {

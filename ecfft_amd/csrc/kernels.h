@@ -28,12 +28,14 @@ template <class F>
 __global__ __launch_bounds__(kBlock) void k_decompose_stage(typename F::elem* __restrict__ buf,
                                                              const typename F::elem* __restrict__ np0,
                                                              const typename F::elem* __restrict__ dinv,
-                                                             uint32_t log_h, size_t npairs) {
+                                                             uint32_t log_h, size_t npairs, uint32_t tstride, uint32_t toff) {
+    // tstride/toff: table entry of local pair index i is i*tstride + toff (cyclic shards of a split EXTEND; 1/0 otherwise)
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= npairs) return;
     size_t h = (size_t)1 << log_h;
     size_t i = g & (h - 1);
     size_t idx = ((g >> log_h) << (log_h + 1)) + i;
+    i = i * tstride + toff;
     typename F::elem a = buf[idx], b = buf[idx + h];
     typename F::elem q1 = F::mul(dinv[i], F::sub(b, a));
     typename F::elem q0 = F::mul_add(np0[i], q1, a);
@@ -45,12 +47,13 @@ template <class F>
 __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __restrict__ buf,
                                                              const typename F::elem* __restrict__ p0,
                                                              const typename F::elem* __restrict__ p1,
-                                                             uint32_t log_h, size_t npairs) {
+                                                             uint32_t log_h, size_t npairs, uint32_t tstride, uint32_t toff) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= npairs) return;
     size_t h = (size_t)1 << log_h;
     size_t i = g & (h - 1);
     size_t idx = ((g >> log_h) << (log_h + 1)) + i;
+    i = i * tstride + toff;
     typename F::elem a = buf[idx], b = buf[idx + h];
     buf[idx] = F::mul_add(p0[i], b, a);
     buf[idx + h] = F::mul_add(p1[i], b, a);
@@ -231,10 +234,10 @@ template <class F>
 __global__ __launch_bounds__(kBlock) void k_scale_by_table(typename F::elem* dst,  // may alias src
                                                             const typename F::elem* src,
                                                             const typename F::elem* __restrict__ tbl,
-                                                            size_t tbl_mask, size_t n) {
+                                                            size_t tbl_mask, size_t n, uint32_t tstride, uint32_t toff) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
-    dst[g] = F::mul(tbl[g & tbl_mask], src[g]);
+    dst[g] = F::mul(tbl[(g & tbl_mask) * tstride + toff], src[g]);
 }
 
 // dst[b*m + 2i]   = u0[i] + xe[i]*v0[i]                (src block  = [u0 | v0])

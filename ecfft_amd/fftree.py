@@ -26,7 +26,8 @@ TBL_F, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV
 
 EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_ctx_destroy", "ecfft_tree_size",
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
-           "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read"]
+           "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
+           "ecfft_extend_top_cyclic", "ecfft_extend_local_block"]
 
 
 class Moiety(enum.IntEnum):
@@ -69,6 +70,8 @@ def lib():
         L.ecfft_tree_table.restype, L.ecfft_tree_table.argtypes = ci, [vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
         L.ecfft_build_points.restype, L.ecfft_build_points.argtypes = ci, [ci, sz, vp, vp, vp]
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
+        L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
+        L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
         L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
         L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
@@ -190,6 +193,23 @@ class FFTree:
         assert total % count == 0
         _check(lib().ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
         return out
+
+    # ---- shards of one EXTEND split over P GPUs (in place; see ecfft_amd/distributed.py) -----
+    def _inplace(self, x):
+        if _is_torch(x):
+            import torch
+            assert x.is_cuda and x.is_contiguous()
+            return x.data_ptr(), MEM_DEVICE, torch.cuda.current_stream(x.device).cuda_stream
+        assert isinstance(x, np.ndarray) and x.flags["C_CONTIGUOUS"] and x.dtype == self.field.dtype
+        return x.ctypes.data, MEM_HOST, None
+
+    def extend_top_cyclic(self, shard, e, moiety, log_p, rank, recombine):
+        ptr, mem, stream = self._inplace(shard)
+        _check(lib().ecfft_extend_top_cyclic(self._h, ptr, e, int(moiety), log_p, rank, int(recombine), mem, stream))
+
+    def extend_local_block(self, shard, e, moiety, log_p):
+        ptr, mem, stream = self._inplace(shard)
+        _check(lib().ecfft_extend_local_block(self._h, ptr, e, int(moiety), log_p, mem, stream))
 
     # ---- benchmarking aid -------------------------------------------------------------------
     def profile(self, on):

@@ -82,6 +82,19 @@ int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int me
  * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend). */
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);
 
+/* Building blocks of ONE EXTEND of e evaluations (tree T_{2e}) split over P = 2^log_p GPUs; the
+ * orchestration (RCCL all-to-all between the block and the cyclic distribution) lives above the ABI,
+ * see ecfft_amd/distributed.py and DESIGN.md section 8.  No reference counterpart (the reference is
+ * single-process); together they compute exactly FFTree::extend (src/fftree.rs:123-126).
+ *   ecfft_extend_top_cyclic : buf = the rank's CYCLIC shard (local j' <-> global j'*P + rank, e/P elements).
+ *                             recombine = 0: multiply by 1/W_src, then decompose stages 0..log_p-1;
+ *                             recombine = 1: recombine stages log_p-1..0, then multiply by W_target.
+ *   ecfft_extend_local_block: buf = the rank's BLOCK shard (global [rank*e/P, (rank+1)*e/P)): every stage
+ *                             k >= log_p, decompose then recombine, with the fused single-GPU kernels. */
+int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int recombine,
+                            int mem, void* stream);
+int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream);
+
 /* copy one table of the subtree with m leaves into host memory (element representation above);
  * returns the number of elements through *count; cap = capacity of host_out in elements. */
 int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);

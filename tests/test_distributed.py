@@ -1,0 +1,61 @@
+"""Multi-process tests of the N>1 paths on CPU (gloo): the split-EXTEND orchestration
+(ecfft_amd/distributed.py: block<->cyclic all_to_all_single + local stage calls) at world sizes 2 and 4."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_extend_sharded_gloo(world, oracle_mod):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("secp256k1", 1 << 8, 2)])
+def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
+    """the HIP shard kernels (cyclic top stages with strided tables, block-local fused stages with
+    k >= log P) emulating P ranks sequentially on one GPU == the single-GPU EXTEND, bit for bit"""
+    import ecfft_amd
+    P = 1 << log_p
+    Fp = ecfft_amd.FIELDS[field]
+    t = Fp.build_fftree(2 * e)
+    rng = np.random.default_rng(5)
+    if field == "m31":
+        x = rng.integers(0, 2**31 - 1, e, dtype=np.uint32)
+    else:
+        x = oracle_mod.field(field).from_ints([int.from_bytes(rng.bytes(32), "little") % (2**256 - 2**32 - 977) for _ in range(e)])
+    for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+        expect = t.extend(x, moiety)
+        c = e // P
+        cyc = [np.ascontiguousarray(x[r::P]) for r in range(P)]                 # block -> cyclic
+        for r in range(P):
+            t.extend_top_cyclic(cyc[r], e, moiety, log_p, r, False)
+        full = np.empty_like(x)
+        for r in range(P):
+            full[r::P] = cyc[r]
+        blk = [np.ascontiguousarray(full[r * c:(r + 1) * c]) for r in range(P)]  # cyclic -> block
+        for r in range(P):
+            t.extend_local_block(blk[r], e, moiety, log_p)
+        full = np.concatenate(blk)
+        cyc = [np.ascontiguousarray(full[r::P]) for r in range(P)]
+        for r in range(P):
+            t.extend_top_cyclic(cyc[r], e, moiety, log_p, r, True)
+        for r in range(P):
+            full[r::P] = cyc[r]
+        assert np.array_equal(full, expect)
