@@ -85,15 +85,7 @@ template <class F>
 class DeviceChain {
 public:
     using E = typename F::elem;
-    struct Tree {
-        size_t m = 0, e = 0; unsigned log_m = 0;
-        E *p0[2] = {}, *p1[2] = {}, *np0[2] = {}, *dinv[2] = {};
-        E *w[2] = {}, *winv[2] = {};
-        E *xe = nullptr, *w1x = nullptr, *A1 = nullptr, *B1 = nullptr, *NB2 = nullptr, *C1 = nullptr, *D1 = nullptr, *xie = nullptr;
-        // the reference's own tables (src/fftree.rs:30-37), plain form, kept for construction/export
-        E *xnn = nullptr, *xnn_inv = nullptr, *z0_s1 = nullptr, *z1_s0 = nullptr, *z0_inv_s1 = nullptr,
-          *z1_inv_s0 = nullptr, *z0z0 = nullptr, *z1z1 = nullptr;
-    };
+    using Tree = LevelTables<E>;   // per-tree table set (kernels.h); an array of them is mirrored on the device
 
     ~DeviceChain() { release(); }
 
@@ -127,13 +119,15 @@ public:
         ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
         // transform scratch: 4 N
         ECFFT_HIP_TRY(hipMalloc(&scratch_, 4 * N_ * sizeof(E)));
-        trees_.resize(L_ + 1);
+        trees_.assign(L_ + 1, Tree{});
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
         }
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
         for (void* p : temps_) (void)hipFree(p);
         temps_.clear();
+        ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
+        ECFFT_HIP_TRY(hipMemcpy(d_trees_, trees_.data(), (L_ + 1) * sizeof(Tree), hipMemcpyHostToDevice));
         return true;
     }
 
@@ -264,12 +258,19 @@ public:
         E* bufA = scratch_; E* bufB = scratch_ + N_; E* work = scratch_ + 2 * N_;
         const E* src = in;
         unsigned ln = ilog2(n);
-        for (unsigned l = 1; l <= ln; ++l) {
+        unsigned l0 = 1;
+        if (ln >= kLogLow) {
+            // levels 1..kLogLow: one launch, one HBM round trip (k_enter_low)
+            E* dst = (ln == kLogLow && out != in) ? out : bufA;
+            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += enter_level_alg_bytes(n, l);
+            ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
+                         2 * (sizeof(E) << kLogLow), s, dst, src, (const Tree*)d_trees_);
+            src = dst; l0 = kLogLow + 1;
+        }
+        for (unsigned l = l0; l <= ln; ++l) {
             const Tree& T = trees_[l];
             size_t e = T.e;
             E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
-            // pre-scale is bookkeeping of the normalised form (0 algorithmic bytes); combine = loop C (:155-159):
-            // reads u0,v0,u1,v1 (2n), x table (m), writes n
             { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, n, 0, s); }
             ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * n + 2.0 * e), k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s,
                          dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), n / 2);
@@ -277,6 +278,16 @@ public:
         }
         if (src != out) (void)hipMemcpyAsync(out, src, n * sizeof(E), hipMemcpyDeviceToDevice, s);
     }
+    // algorithmic bytes of one ENTER / EXIT level in the stage-streaming model
+    static double enter_level_alg_bytes(size_t n, unsigned l) {
+        double e = (double)((size_t)1 << (l - 1));
+        return sizeof(E) * (4.0 * (l - 1) * (double)n + 8.0 * (e - 1) + 3.0 * (double)n + 2.0 * e);
+    }
+    static double exit_level_alg_bytes(size_t n, unsigned l) {
+        double e = (double)((size_t)1 << (l - 1));
+        return sizeof(E) * (8.0 * (l - 1) * (double)n + 32.0 * (e - 1) + 8.5 * (double)n + 8.5 * e);
+    }
+    static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
     void exit(const E* in, E* out, size_t n, hipStream_t s) const {
@@ -285,11 +296,10 @@ public:
         const E* cur = in;
         unsigned ln = ilog2(n);
         size_t nh = n / 2;
-        for (unsigned l = ln; l >= 1; --l) {
+        unsigned l_stop = ln >= kLogLow ? kLogLow : 0;      // levels l_stop..1 run fused in k_exit_low
+        for (unsigned l = ln; l > l_stop; --l) {
             const Tree& T = trees_[l];
-            unsigned le = ilog2(T.e);
             E* dst = (l == 1 && out != in) ? out : (cur == bufA ? bufB : bufA);
-            dim3 g(nblocks(nh)), b(kBlock);
             // The reference's pointwise steps of this level (8.5 n + 8.5 e algorithmic element moves)
             // are all folded into the first load / last store of the four EXTEND cores:
             //   core 1  load  t0 = e0 * (xinv_even / W0)                    [t0 = e0/a0        : n + e   ]
@@ -311,7 +321,13 @@ public:
             IoDesc<E> io4 = io_plain(G, dst);
             io4.st_mode = ST_EXIT_SPLIT; io4.st_a = T.w[0]; io4.st_b = T.xie; io4.aux = cur; io4.aux_stride = 2; io4.aux_off = 0;
             extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee));
-            (void)g; (void)b; (void)le;
+            cur = dst;
+        }
+        if (l_stop) {
+            E* dst = out != in ? out : (cur == bufA ? bufB : bufA);
+            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += exit_level_alg_bytes(n, l);
+            ECFFT_LAUNCH(KC_FUSED_EXIT, bytes, (k_exit_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
+                         2 * (sizeof(E) << kLogLow), s, dst, cur, (const Tree*)d_trees_);
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
@@ -336,6 +352,8 @@ private:
         temps_.clear();
         if (arena_) (void)hipFree(arena_);
         if (scratch_) (void)hipFree(scratch_);
+        if (d_trees_) (void)hipFree(d_trees_);
+        d_trees_ = nullptr;
         arena_ = nullptr; scratch_ = nullptr;
     }
 
@@ -565,6 +583,7 @@ private:
     E* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
     E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr;
     std::vector<Tree> trees_;
+    Tree* d_trees_ = nullptr;
     std::vector<void*> temps_;
     std::mutex mu_;
     mutable Profiler prof_;

@@ -227,6 +227,156 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_col(IoDesc<typename F::ele
 }
 
 // ---------------------------------------------------------------------------------------------
+// Whole low levels of ENTER / EXIT in LDS.  Level m <= tile only touches data inside one tile-aligned
+// block, so the first log(tile) levels of ENTER (bottom-up) and the last log(tile) levels of EXIT
+// (top-down) run in ONE launch with a single HBM round trip: every pre-scale, butterfly stage and
+// pointwise step of those levels happens in LDS.  `LevelTables` is the per-tree table set of
+// device_tree.h (DeviceChain::Tree), indexed by log2(m).
+// ---------------------------------------------------------------------------------------------
+template <class E>
+struct LevelTables {
+    size_t m, e; unsigned log_m;
+    E *p0[2], *p1[2], *np0[2], *dinv[2];
+    E *w[2], *winv[2];
+    E *xe, *w1x, *A1, *B1, *NB2, *C1, *D1, *xie;
+    E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
+};
+
+// every stage (decompose then recombine) of EXTEND on `len` LDS elements = len/e vectors of length e;
+// srcpar = parity of the source moiety.  Ends with a barrier.
+template <class F>
+__device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<typename F::elem>& T, int srcpar) {
+    using E = typename F::elem;
+    const uint32_t tid = threadIdx.x, npairs = len >> 1;
+    const size_t e = (size_t)1 << log_e;
+    const int tgt = 1 - srcpar;
+    for (uint32_t k = 0; k < log_e; ++k) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const E* tn = T.np0[srcpar] + (e - 2 * (size_t)h);
+        const E* td = T.dinv[srcpar] + (e - 2 * (size_t)h);
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+            E x = a[idx], y = a[idx + h];
+            E q1 = F::mul(td[i], F::sub(y, x));
+            E q0 = F::mul_add(tn[i], q1, x);
+            a[idx] = q0; a[idx + h] = q1;
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = log_e; k-- > 0;) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const E* t0 = T.p0[tgt] + (e - 2 * (size_t)h);
+        const E* t1 = T.p1[tgt] + (e - 2 * (size_t)h);
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+            E x = a[idx], y = a[idx + h];
+            a[idx] = F::mul_add(t0[i], y, x);
+            a[idx + h] = F::mul_add(t1[i], y, x);
+        }
+        __syncthreads();
+    }
+}
+
+// ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
+template <class F, int LOG_TILE>
+__global__ __launch_bounds__(kBlockLds) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+                                                          const LevelTables<typename F::elem>* __restrict__ trees) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, npairs = T >> 1;
+    constexpr int PAIRS = (int)(npairs / kBlockLds);     // compile-time trip counts keep ev/od in registers
+    static_assert(PAIRS >= 1 && npairs % kBlockLds == 0, "tile too small for the workgroup");
+    const uint32_t tid = threadIdx.x;
+    E* cur = reinterpret_cast<E*>(ecfft_smem);
+    E* work = cur + T;
+    const size_t base = (size_t)blockIdx.x << log_tile;
+    for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    __syncthreads();
+    for (uint32_t l = 1; l <= log_tile; ++l) {
+        const LevelTables<E>& L = trees[l];
+        const uint32_t le = l - 1, e = 1u << le;
+        for (uint32_t j = tid; j < T; j += kBlockLds) work[j] = F::mul(L.winv[0][j & (e - 1)], cur[j]);
+        __syncthreads();
+        lds_extend_core<F>(work, T, le, L, 0);
+        // combine (:155-159): block [u0|v0] + extended [U1|V1] -> interleaved evaluations; results are held in
+        // registers across the barrier because the interleaving store overwrites other threads' inputs
+        E ev[PAIRS], od[PAIRS];
+#pragma unroll
+        for (int c = 0; c < PAIRS; ++c) {
+            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            E u0 = cur[bb + i], v0 = cur[bb + e + i], U1 = work[bb + i], V1 = work[bb + e + i];
+            ev[c] = F::mul_add(L.xe[i], v0, u0);
+            od[c] = F::mul_add(L.w1x[i], V1, F::mul(L.w[1][i], U1));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < PAIRS; ++c) {
+            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            cur[bb + 2 * i] = ev[c]; cur[bb + 2 * i + 1] = od[c];
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = cur[j];
+}
+
+// EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
+// DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
+template <class F, int LOG_TILE>
+__global__ __launch_bounds__(kBlockLds) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+                                                         const LevelTables<typename F::elem>* __restrict__ trees) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, nh = T >> 1;
+    constexpr int PAIRS = (int)(nh / kBlockLds);
+    static_assert(PAIRS >= 1 && nh % kBlockLds == 0, "tile too small for the workgroup");
+    const uint32_t tid = threadIdx.x;
+    E* cur = reinterpret_cast<E*>(ecfft_smem);
+    E* G = cur + T;
+    E* H = G + nh;
+    const size_t base = (size_t)blockIdx.x << log_tile;
+    for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    __syncthreads();
+    for (uint32_t l = log_tile; l >= 1; --l) {
+        const LevelTables<E>& L = trees[l];
+        const uint32_t le = l - 1, e = 1u << le;
+        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::mul(L.A1[g & (e - 1)], cur[2 * g]);
+        __syncthreads();
+        lds_extend_core<F>(G, nh, le, L, 0);
+        for (uint32_t g = tid; g < nh; g += kBlockLds) {
+            uint32_t i = g & (e - 1);
+            E r = F::mul_add(L.NB2[i], G[g], F::mul(L.B1[i], cur[2 * g + 1]));
+            G[g] = r; H[g] = r;
+        }
+        __syncthreads();
+        lds_extend_core<F>(G, nh, le, L, 1);
+        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::mul(L.C1[g & (e - 1)], G[g]);
+        __syncthreads();
+        lds_extend_core<F>(G, nh, le, L, 0);
+        for (uint32_t g = tid; g < nh; g += kBlockLds) {
+            uint32_t i = g & (e - 1);
+            G[g] = F::mul_add(L.NB2[i], G[g], F::mul(L.D1[i], H[g]));
+        }
+        __syncthreads();
+        lds_extend_core<F>(G, nh, le, L, 1);
+        E u[PAIRS], v[PAIRS];
+#pragma unroll
+        for (int c = 0; c < PAIRS; ++c) {
+            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1);
+            u[c] = F::mul(L.w[0][i], G[g]);
+            v[c] = F::mul(L.xie[i], F::sub(cur[2 * g], u[c]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < PAIRS; ++c) {
+            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            cur[bb + i] = u[c]; cur[bb + e + i] = v[c];
+        }
+        __syncthreads();
+    }
+    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = cur[j];
+}
+
+// ---------------------------------------------------------------------------------------------
 // pointwise kernels of ENTER (src/fftree.rs:143-161) — level m, e = m/2, n/m blocks
 // ---------------------------------------------------------------------------------------------
 // work[j] = src[j] * winv0[j mod e]

@@ -13,12 +13,16 @@ using F = Secp256k1;
 #define ITER 512
 #endif
 
+__device__ unsigned long long g_cycles[2];
 __global__ __launch_bounds__(256) void k_chain(const Fe256* t, const Fe256* c, Fe256* x) {
     size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     Fe256 tv = t[g], cv = c[g], xv = x[g];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int i = 0; i < ITER; ++i) xv = F::mul_add(tv, xv, cv);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
     x[g] = xv;
+    if (g == 0) { g_cycles[0] = t1 - t0; }
 }
 
 int main() {
@@ -55,6 +59,8 @@ int main() {
         }
         double wave_ops = (double)grid * 4 * ITER;
         double cyc = best * 1e-3 * 2.4e9 / (wave_ops / 1024.0);
+        unsigned long long cyc_dev[2]; (void)hipMemcpyFromSymbol(cyc_dev, HIP_SYMBOL(g_cycles), sizeof(cyc_dev));
+        printf("   [s_memtime delta of wave 0: %llu ticks over ~%.3f ms => %.0f MHz if 1 tick = 1 shader clock]\n", cyc_dev[0], best, cyc_dev[0] / (best * 1e3));
         printf("waves/SIMD %d: %.3f ms, %.1f cycles/wave-op/SIMD @2.4GHz, %.3e field-mul/s chip-wide\n", wpb, best, cyc,
                (double)grid * 256 * ITER / (best * 1e-3));
     }
