@@ -5,6 +5,15 @@ import sqlite3
 import sys
 
 
+def hot(db_path, sub, last):
+    """average duration of the LAST `last` dispatches of kernels whose name contains `sub` (the timed steps)"""
+    import json
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select end - start from kernels where name like ? order by start desc limit ?", (f"%{sub}%", last)).fetchall()
+    d = [r[0] for r in rows]
+    print(json.dumps({"kernel": sub, "dispatches": len(d), "avg_us": sum(d) / max(len(d), 1) / 1e3, "total_ms": sum(d) / 1e6}))
+
+
 def main(db_path, title):
     db = sqlite3.connect(db_path)
     rows = db.execute(
@@ -20,4 +29,7 @@ def main(db_path, title):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else sys.argv[1])
+    if "--kernel" in sys.argv:
+        hot(sys.argv[1], sys.argv[sys.argv.index("--kernel") + 1], int(sys.argv[sys.argv.index("--last") + 1]))
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else sys.argv[1])

@@ -1,16 +1,24 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of the bench command.
-# Usage: tools/profile_gpu.sh <tag> [bench args...]; outputs under gpurun_out/prof_<tag>/
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of the bench command; keeps only
+# the text summaries (the rocpd databases exceed gpurun's 64 MiB return limit).
+# Usage: tools/profile_gpu.sh <tag> <dominant-kernel-substring> <hot-path launches of it = (steps+warmup)*launches_per_step> [bench args...]
 set -u
-TAG=$1; shift
+TAG=$1; KERN=$2; LAST=$3; shift 3
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python bench.py --steps 3 --warmup 1 --no-profile --cpu-log-n 0 $*"
+echo "$CMD" > $OUT/command.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
-# PMC passes: counters in their own runs, kernel-trace only (no other trace domains)
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
-ls -R $OUT | head -30
-tail -2 $OUT/trace.log
+python tools/prof_summary.py $OUT/trace/trace_results.db "rocprofv3 --kernel-trace --stats -- $CMD" > $OUT/kernel_stats.md
+python tools/prof_summary.py $OUT/trace/trace_results.db x --kernel "$KERN" --last $LAST > $OUT/kernel_hot.json
+rm -rf $OUT/trace
+for P in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+  N=$(echo $P | cut -d' ' -f1)
+  timeout 300 rocprofv3 --kernel-trace --pmc $P -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/pmc_$N.log 2>&1
+  python tools/pmc_summary.py $OUT/pmc_$N/pmc_results.db > $OUT/pmc_$N.md 2>&1
+  python tools/pmc_summary.py $OUT/pmc_$N/pmc_results.db --kernel "$KERN" --last $LAST > $OUT/pmc_${N}_hot.json 2>&1
+  rm -rf $OUT/pmc_$N
+done
+grep -h '"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line.json
+ls -la $OUT
