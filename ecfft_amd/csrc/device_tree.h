@@ -148,7 +148,7 @@ public:
 #define ECFFT_LOG_TILE_BYTES 15
 #endif
     static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
-    static constexpr unsigned kColStages = 4;
+    static constexpr unsigned kColStages = 5;      // max stages per column pass (rows of tile/32 elements = 1 KiB stay coalesced)
     void extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
                      double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
@@ -162,7 +162,11 @@ public:
         // pass list: (kind, ka, kb)
         struct Pass { int kind; unsigned ka, kb; };                           // kind 0 col-decompose, 1 row, 2 col-recombine
         Pass passes[2 * 8 + 1]; int np = 0;
-        for (unsigned k = k_begin; k < k_first; k += kColStages) { unsigned kb = k + kColStages - 1 < k_first - 1 ? k + kColStages - 1 : k_first - 1; passes[np++] = {0, k, kb}; }
+        if (k_first > k_begin) {                                              // balanced groups of <= kColStages stages
+            unsigned ncol = k_first - k_begin, ngrp = (ncol + kColStages - 1) / kColStages;
+            unsigned k = k_begin;
+            for (unsigned g = 0; g < ngrp; ++g) { unsigned sz = ncol / ngrp + (g < ncol % ngrp ? 1 : 0); passes[np++] = {0, k, k + sz - 1}; k += sz; }
+        }
         int nd = np;
         passes[np++] = {1, k_first, le};
         for (int g = nd - 1; g >= 0; --g) passes[np++] = {2, passes[g].ka, passes[g].kb};
@@ -182,7 +186,7 @@ public:
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum) + extra;
                 ECFFT_LAUNCH(KC_ROW, bytes, k_stages_lds<F>, dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
-                             ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], le, k_first, log_tile);
+                             ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
             } else {
                 unsigned R = P.kb - P.ka + 1, log_c = log_tile - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
@@ -480,6 +484,19 @@ private:
                 w[i] = U;
             });
             batch_inv(T.w[sg], T.winv[sg], e, s);
+        }
+        // merged innermost stage pair (h = 1, stage k = le-1): out_j = a + c_j*(b - a) with
+        // c_j = (p_j^target - p_0^source) / (p_1^source - p_0^source), table offset e-2 (kernels.h)
+        for (int sg = 0; sg < 2; ++sg) {
+            T.inner[sg] = take(2);
+            if (e > 1) {
+                E* in = T.inner[sg];
+                const E *sp0 = T.p0[sg] + (e - 2), *sdi = T.dinv[sg] + (e - 2), *tp0 = T.p0[1 - sg] + (e - 2), *tp1 = T.p1[1 - sg] + (e - 2);
+                foreach_n(s, 1, [=] __device__(size_t) {
+                    in[0] = F::mul(F::sub(tp0[0], sp0[0]), sdi[0]);
+                    in[1] = F::mul(F::sub(tp1[0], sp0[0]), sdi[0]);
+                });
+            }
         }
         T.z0_s1 = take(es); T.z1_s0 = take(es); T.z0_inv_s1 = take(es); T.z1_inv_s0 = take(es);
         T.z0z0 = take(m); T.z1z1 = take(m);

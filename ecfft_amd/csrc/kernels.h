@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::ele
                                                            const typename F::elem* __restrict__ dinv,
                                                            const typename F::elem* __restrict__ p0,
                                                            const typename F::elem* __restrict__ p1,
+                                                           const typename F::elem* __restrict__ inner,
                                                            uint32_t log_e, uint32_t k_first, uint32_t log_tile) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -138,7 +139,10 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::ele
     for (uint32_t j = tid; j < T; j += kBlockLds) tile[j] = io_load<F>(io, base + j, emask);
     __syncthreads();
     const uint32_t npairs = T >> 1;
-    for (uint32_t k = k_first; k < log_e; ++k) {
+    // stages k_first .. log_e-2 (h >= 2); the two innermost stages (decompose h=1, recombine h=1) act on the
+    // same pairs back to back and are merged into out_j = a + c_j*(b - a): 2 multiplies instead of 4
+    const uint32_t k_inner = log_e ? log_e - 1 : 0;
+    for (uint32_t k = k_first; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* tn = np0 + (e - 2 * (size_t)h);
         const E* td = dinv + (e - 2 * (size_t)h);
@@ -151,7 +155,17 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::ele
         }
         __syncthreads();
     }
-    for (uint32_t k = log_e; k-- > k_first;) {
+    if (log_e > 0) {
+        const E c0 = inner[0], c1 = inner[1];
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            E a = tile[2 * g], b = tile[2 * g + 1];
+            E d = F::sub(b, a);
+            tile[2 * g] = F::mul_add(c0, d, a);
+            tile[2 * g + 1] = F::mul_add(c1, d, a);
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = k_inner; k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* t0 = p0 + (e - 2 * (size_t)h);
         const E* t1 = p1 + (e - 2 * (size_t)h);
@@ -239,6 +253,7 @@ struct LevelTables {
     E *p0[2], *p1[2], *np0[2], *dinv[2];
     E *w[2], *winv[2];
     E *xe, *w1x, *A1, *B1, *NB2, *C1, *D1, *xie;
+    E *inner[2];   // inner[srcpar] = {c0, c1}: the merged innermost (h = 1) decompose+recombine stage, out_j = a + c_j*(b - a)
     E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
 };
 
@@ -250,7 +265,8 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
-    for (uint32_t k = 0; k < log_e; ++k) {
+    const uint32_t k_inner = log_e ? log_e - 1 : 0;
+    for (uint32_t k = 0; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* tn = T.np0[srcpar] + (e - 2 * (size_t)h);
         const E* td = T.dinv[srcpar] + (e - 2 * (size_t)h);
@@ -263,7 +279,17 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
         }
         __syncthreads();
     }
-    for (uint32_t k = log_e; k-- > 0;) {
+    if (log_e > 0) {                                    // merged innermost stage pair (h = 1)
+        const E c0 = T.inner[srcpar][0], c1 = T.inner[srcpar][1];
+        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+            E x = a[2 * g], y = a[2 * g + 1];
+            E d = F::sub(y, x);
+            a[2 * g] = F::mul_add(c0, d, x);
+            a[2 * g + 1] = F::mul_add(c1, d, x);
+        }
+        __syncthreads();
+    }
+    for (uint32_t k = k_inner; k-- > 0;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* t0 = T.p0[tgt] + (e - 2 * (size_t)h);
         const E* t1 = T.p1[tgt] + (e - 2 * (size_t)h);

@@ -21,6 +21,9 @@ def pair_name(k):
     return f"E{k // 2}" if k % 2 == 0 else f"O{(k - 1) // 2}"
 
 
+GROUP = int(os.environ.get("ECFFT_MUL_GROUP", "0"))   # >0: carries go to distinct SGPR pairs, mads issued in groups of GROUP before their addc's
+
+
 def gen_product(has_c):
     """returns list of C++ lines; defines E0..E7, O0..O6 (uint64_t) and X<k> overflow words (uint32_t)"""
     lines = []
@@ -59,7 +62,45 @@ def gen_product(has_c):
             for q in range(4):
                 c_idx[2 * q] = nout + len(in_names); in_names.append(f"c{q}")
         t_op = nout
-        for j in range(8):
+        if GROUP:
+            # carry-outs to distinct SGPR pairs (asm temporaries), so that mads of different accumulators do not
+            # serialise on VCC; the addc's of a group follow the group's mads
+            ncar = 8
+            car0 = len(outs)
+            for q in range(ncar):
+                outs.append((f"cy{q}", "=&s"))
+            shift = ncar
+            nout2 = len(outs)
+            def inop(idx):   # input operand numbers move up by the extra outputs
+                return idx + shift
+            t_op2 = inop(t_op)
+            pend = []
+            for j in range(8):
+                k = i + j
+                first = seen[k] == 0
+                P = pair_idx[k]
+                xj = inop(nout + 1 + j)
+                cy = car0 + j
+                if first and k in c_idx:
+                    body.append(f"v_mad_u64_u32 %{P}, %{cy}, %{t_op2}, %{xj}, %{inop(c_idx[k])}")
+                elif first:
+                    body.append(f"v_mad_u64_u32 %{P}, %{cy}, %{t_op2}, %{xj}, 0")
+                else:
+                    body.append(f"v_mad_u64_u32 %{P}, %{cy}, %{t_op2}, %{xj}, %{P}")
+                if k in ex_idx:
+                    xi, fresh = ex_idx[k]
+                    pend.append((xi, fresh, cy))
+                    ex_live[k] = True
+                seen[k] += 1
+                if (j + 1) % GROUP == 0 or j == 7:
+                    for xi, fresh, cyq in pend:
+                        if fresh:
+                            body.append(f"v_addc_co_u32_e64 %{xi}, %{cyq}, 0, 0, %{cyq}")
+                        else:
+                            body.append(f"v_addc_co_u32_e64 %{xi}, %{cyq}, 0, %{xi}, %{cyq}")
+                    pend = []
+        else:
+          for j in range(8):
             k = i + j
             first = seen[k] == 0
             P = pair_idx[k]
@@ -84,6 +125,8 @@ def gen_product(has_c):
         lines.append(f'        asm("{asm}"\n            : {outs_s}\n            : {ins_s}\n            : "vcc");')
     assert all(seen[k] == nprod[k] for k in range(15))
     decl = "        uint32_t " + ", ".join(ex_decl) + ";"
+    if GROUP:
+        decl += "\n        uint64_t cy0, cy1, cy2, cy3, cy4, cy5, cy6, cy7;"
     if has_c:
         cdecl = ["        const uint64_t c%d = (uint64_t)c.l[%d] | ((uint64_t)c.l[%d] << 32);" % (q, 2 * q, 2 * q + 1) for q in range(4)]
     else:
