@@ -337,6 +337,72 @@ public:
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
     }
 
+    // ------------------------------------------------------------------------------------------
+    // Public wrappers of the remaining FFTree algorithms on USER data (crate representation),
+    // composed from the same EXTEND kernels.  Device pointers; synchronous (they drain `s` before returning
+    // because they use temporaries).  Caller holds lock().
+    // ------------------------------------------------------------------------------------------
+    bool api_mextend(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) {     // src/fftree.rs:138-141
+        b_mextend(ilog2(e) + 1, in, out, count, target, s, true);
+        return finish_api(s);
+    }
+    // redc_z0 / redc_z1 (src/fftree.rs:264-275): evals, a: n entries
+    bool api_redc(const E* evals, const E* a, E* out, size_t n, int moiety, hipStream_t s) {
+        unsigned l = ilog2(n); size_t e = n / 2;
+        E* a0i = temp(e); E* a1 = temp(e);
+        plain_halves(a, a0i, a1, e, s);
+        batch_inv(a0i, a0i, e, s);                                          // the reference inverts a0 on every call (:235)
+        b_redc(l, evals, a0i, a1, out, moiety, s);
+        return finish_api(s);
+    }
+    // modular_reduce (src/fftree.rs:286-289)
+    bool api_modular_reduce(const E* evals, const E* a, const E* c, E* out, size_t n, hipStream_t s) {
+        unsigned l = ilog2(n); size_t e = n / 2;
+        E* a0i = temp(e); E* a1 = temp(e); E* cp = temp(n);
+        plain_halves(a, a0i, a1, e, s);
+        batch_inv(a0i, a0i, e, s);
+        { const E rinv = rinv_; foreach_n(s, n, [=] __device__(size_t i) { cp[i] = F::mul(c[i], rinv); }); }
+        b_modular_reduce(l, evals, a0i, a1, cp, out, s);
+        return finish_api(s);
+    }
+    // vanish (src/fftree.rs:313-316): nd domain points -> 2*nd evaluations on the leaves of T_{2 nd}
+    bool api_vanish(const E* dom, E* out, size_t nd, hipStream_t s) {
+        b_vanish(ilog2(nd) + 1, dom, out, s, true);
+        return finish_api(s);
+    }
+    // degree (src/fftree.rs:195-198), data-dependent recursion driven from the host: one flag read per level
+    bool api_degree(const E* evals, size_t n, hipStream_t s, size_t* degree) {
+        size_t deg = 0;
+        if (n > 1) {
+            E* cur = temp(n); E* e0 = temp(n / 2); E* e1 = temp(n / 2); E* g1 = temp(n / 2);
+            int* flag = nullptr;
+            if (hipMalloc(&flag, sizeof(int)) != hipSuccess) return false;
+            temps_.push_back(flag);
+            (void)hipMemcpyAsync(cur, evals, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+            for (size_t m = n; m >= 2; m >>= 1) {
+                unsigned l = ilog2(m); size_t e = m / 2;
+                const Tree& T = trees_[l];
+                foreach_n(s, e, [=] __device__(size_t i) { e0[i] = cur[2 * i]; e1[i] = cur[2 * i + 1]; });
+                b_extend(l, e0, g1, 1, 1, s);                               // :180
+                (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+                foreach_n(s, e, [=] __device__(size_t i) { if (!F::eq(g1[i], e1[i])) atomicOr(flag, 1); });
+                int hflag = 0;
+                if (hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+                if (hipStreamSynchronize(s) != hipSuccess) return false;
+                if (!hflag) {                                               // degree < m/2 (:181-183)
+                    (void)hipMemcpyAsync(cur, e0, e * sizeof(E), hipMemcpyDeviceToDevice, s);
+                } else {                                                    // :187-191
+                    const E* zi = T.z0_inv_s1;
+                    foreach_n(s, e, [=] __device__(size_t i) { e1[i] = F::mul(F::sub(e1[i], g1[i]), zi[i]); });
+                    b_extend(l, e1, cur, 1, 0, s);
+                    deg += e;
+                }
+            }
+        }
+        *degree = deg;
+        return finish_api(s);
+    }
+
     E* scratch() const { return scratch_; }
 
 private:
@@ -361,6 +427,18 @@ private:
         arena_ = nullptr; scratch_ = nullptr;
     }
 
+    bool finish_api(hipStream_t s) {
+        bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        for (void* p : temps_) (void)hipFree(p);
+        temps_.clear();
+        return ok;
+    }
+    // user table a (crate representation, 2e entries) -> plain even entries (to be inverted) and plain odd entries
+    void plain_halves(const E* a, E* a_even, E* a_odd, size_t e, hipStream_t s) {
+        const E rinv = rinv_;
+        foreach_n(s, e, [=] __device__(size_t i) { a_even[i] = F::mul(a[2 * i], rinv); a_odd[i] = F::mul(a[2 * i + 1], rinv); });
+    }
+
     // ---- construction-time device primitives (plain data) ----
     // out[i] = 1/in[i]; chunks of 8 share one Fermat inversion (Montgomery's trick)
     void batch_inv(const E* in, E* out, size_t n, hipStream_t s) {
@@ -383,28 +461,32 @@ private:
         extend(in, out, trees_[log_m].e, count, target, s);
     }
     // mextend (src/fftree.rs:128-141)
-    void b_mextend(unsigned log_m, const E* in, E* out, size_t count, int target, hipStream_t s) {
+    // The compositions below run on PLAIN data during construction (mont = false) and on user data in the crate's
+    // Montgomery form for the public wrappers (mont = true): tables that are ADDED to data are converted with to_mont,
+    // data x data products get the extra factor R^-1 (rinv_), data x table products need nothing.
+    void b_mextend(unsigned log_m, const E* in, E* out, size_t count, int target, hipStream_t s, bool mont = false) {
         const Tree& T = trees_[log_m];
         b_extend(log_m, in, out, count, target, s);
         const E* z = target == 1 ? T.z0_s1 : T.z1_s0;
         size_t mask = T.e - 1;
-        foreach_n(s, T.e * count, [=] __device__(size_t i) { out[i] = F::add(out[i], z[i & mask]); });
+        foreach_n(s, T.e * count, [=] __device__(size_t i) { E zz = z[i & mask]; out[i] = F::add(out[i], mont ? F::to_mont(zz) : zz); });
     }
-    // redc_impl with moiety S0 (src/fftree.rs:232-259); a0inv/a1: e entries; evals/out: m entries
-    void b_redc_s0(unsigned log_m, const E* evals, const E* a0inv, const E* a1, E* out, hipStream_t s) {
+    // redc_impl (src/fftree.rs:232-259); a0inv/a1: e PLAIN entries; evals/out: m entries
+    void b_redc(unsigned log_m, const E* evals, const E* a0inv, const E* a1, E* out, int moiety, hipStream_t s) {
         const Tree& T = trees_[log_m];
         size_t e = T.e;
         E* t0 = temp(e); E* h1 = temp(e);
         foreach_n(s, e, [=] __device__(size_t i) { t0[i] = F::mul(evals[2 * i], a0inv[i]); });
-        b_extend(log_m, t0, t0, 1, 1, s);                                   // g1 on S1
-        const E* zinv = T.z0_inv_s1;
+        b_extend(log_m, t0, t0, 1, 1 - moiety, s);                           // g1 = extend_impl(t0, opposite moiety)  (:239-245)
+        const E* zinv = moiety == 0 ? T.z0_inv_s1 : T.z1_inv_s0;            // :247-250
         foreach_n(s, e, [=] __device__(size_t i) {
             h1[i] = F::mul(F::sub(evals[2 * i + 1], F::mul(t0[i], a1[i])), zinv[i]);
         });
-        b_extend(log_m, h1, t0, 1, 0, s);                                   // h0 on S0
+        b_extend(log_m, h1, t0, 1, moiety, s);                               // h0 = extend_impl(h1, moiety)  (:256)
         foreach_n(s, e, [=] __device__(size_t i) { out[2 * i] = t0[i]; out[2 * i + 1] = h1[i]; });
     }
-    // modular_reduce_impl (src/fftree.rs:277-281)
+    void b_redc_s0(unsigned log_m, const E* evals, const E* a0inv, const E* a1, E* out, hipStream_t s) { b_redc(log_m, evals, a0inv, a1, out, 0, s); }
+    // modular_reduce_impl (src/fftree.rs:277-281); c PLAIN
     void b_modular_reduce(unsigned log_m, const E* evals, const E* a0inv, const E* a1, const E* c, E* out, hipStream_t s) {
         size_t m = trees_[log_m].m;
         E* h = temp(m);
@@ -413,22 +495,25 @@ private:
         b_redc_s0(log_m, h, a0inv, a1, out, s);
     }
     // vanish_impl (src/fftree.rs:291-308), bottom-up: dom has e = m/2 entries, out m entries
-    void b_vanish(unsigned log_m, const E* dom, E* out, hipStream_t s) {
+    void b_vanish(unsigned log_m, const E* dom, E* out, hipStream_t s, bool mont = false) {
         const Tree& T = trees_[log_m];
         size_t e = T.e, m = T.m;
         E* Q = temp(m); E* Q2 = temp(m); E* q0 = temp(e); E* q1 = temp(e);
-        const E* f = f_; size_t N = N_;
+        const E* f = f_; size_t N = N_; const E rinv = rinv_;
         foreach_n(s, e, [=] __device__(size_t i) {        // T_2 leaves are the top tree's leaves 0 and N/2
-            Q[2 * i] = F::sub(dom[i], f[N]); Q[2 * i + 1] = F::sub(dom[i], f[N + N / 2]);
+            E l0 = f[N], l1 = f[N + N / 2];
+            if (mont) { l0 = F::to_mont(l0); l1 = F::to_mont(l1); }
+            Q[2 * i] = F::sub(dom[i], l0); Q[2 * i + 1] = F::sub(dom[i], l1);
         });
         unsigned le = ilog2(e);
         for (unsigned r = 1; r <= le; ++r) {
             size_t bs = (size_t)1 << r;                     // size of the blocks being merged
             foreach_n(s, e, [=] __device__(size_t g) {
                 size_t b = g >> r, i = g & (bs - 1);
-                q0[g] = F::mul(Q[(2 * b) * bs + i], Q[(2 * b + 1) * bs + i]);
+                E pr = F::mul(Q[(2 * b) * bs + i], Q[(2 * b + 1) * bs + i]);
+                q0[g] = mont ? F::mul(pr, rinv) : pr;
             });
-            b_mextend(r + 1, q0, q1, e >> r, 1, s);
+            b_mextend(r + 1, q0, q1, e >> r, 1, s, mont);
             E* dstQ = (r == le) ? out : Q2;
             foreach_n(s, e, [=] __device__(size_t g) { dstQ[2 * g] = q0[g]; dstQ[2 * g + 1] = q1[g]; });
             E* t = Q; Q = Q2; Q2 = t;
@@ -596,6 +681,7 @@ private:
     }
 
     HostTree<F> host_;
+    E rinv_ = F::inv(F::to_mont(F::one()));   // R^-1 as a plain residue (1 for M31)
     size_t N_ = 0; unsigned L_ = 0; int device_ = 0;
     E* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
     E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr;

@@ -15,7 +15,9 @@ struct ecfft_ctx {
     std::unique_ptr<DeviceChain<M31>> m31;
     void* stage = nullptr;       // device staging for host-pointer calls (in + out), lazily sized
     size_t stage_bytes = 0;
-    ~ecfft_ctx() { if (stage) (void)hipFree(stage); }
+    hipEvent_t last_op = nullptr;   // completion of the previous transform on this context: calls on other streams wait for
+                                    // it before touching the shared scratch buffers (contexts serialise, see ecfft_hip.h)
+    ~ecfft_ctx() { if (stage) (void)hipFree(stage); if (last_op) (void)hipEventDestroy(last_op); }
 };
 
 namespace {
@@ -55,6 +57,13 @@ bool ensure_stage(ecfft_ctx* c, size_t bytes) {
     return true;
 }
 
+// order this call after the previous one on the same context, whatever streams they use
+bool op_begin(ecfft_ctx* c, hipStream_t s) {
+    if (!c->last_op) return hipEventCreateWithFlags(&c->last_op, hipEventDisableTiming) == hipSuccess;
+    return hipStreamWaitEvent(s, c->last_op, 0) == hipSuccess;
+}
+bool op_end(ecfft_ctx* c, hipStream_t s) { return hipEventRecord(c->last_op, s) == hipSuccess; }
+
 enum Op { OP_ENTER, OP_EXIT, OP_EXTEND };
 
 template <class F>
@@ -71,6 +80,7 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
     std::lock_guard<std::mutex> guard(ch.lock());
+    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
     size_t total = len * count, bytes = total * sizeof(E);
     const E* din = (const E*)in; E* dout = (E*)out;
     if (mem == ECFFT_MEM_HOST) {
@@ -88,9 +98,11 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
     if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
     if (mem == ECFFT_MEM_HOST) {
         if (hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
+        if (!op_end(c, s)) return ECFFT_ERR_HIP;
         if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
+        return ECFFT_OK;
     }
-    return ECFFT_OK;
+    return op_end(c, s) ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
 template <class F>
@@ -147,6 +159,7 @@ int run_shard(ecfft_ctx* c, DeviceChain<F>& ch, void* buf, size_t e, int moiety,
     if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> guard(ch.lock());
+    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
     size_t bytes = (e >> log_p) * sizeof(E);
     E* d = (E*)buf;
     if (mem == ECFFT_MEM_HOST) {
@@ -159,11 +172,69 @@ int run_shard(ecfft_ctx* c, DeviceChain<F>& ch, void* buf, size_t e, int moiety,
     if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
     if (mem == ECFFT_MEM_HOST) {
         if (hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
+        if (!op_end(c, s)) return ECFFT_ERR_HIP;
         if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
+        return ECFFT_OK;
     }
-    return ECFFT_OK;
+    return op_end(c, s) ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 }  // namespace
+
+
+// ---- remaining algorithms: generic driver with up to 3 inputs and 1 output, staged through device temporaries for host buffers
+enum Alg { ALG_MEXTEND, ALG_REDC, ALG_MOD, ALG_VANISH, ALG_DEGREE };
+template <class F>
+int run_alg(ecfft_ctx* c, DeviceChain<F>& ch, Alg alg, const void* in0, const void* in1, const void* in2, void* out, size_t len,
+            size_t count, int moiety, int mem, void* stream, size_t* degree) {
+    using E = typename F::elem;
+    if (!in0 || (alg != ALG_DEGREE && !out)) return ECFFT_ERR_BAD_ARG;
+    if ((alg == ALG_REDC || alg == ALG_MOD) && !in1) return ECFFT_ERR_BAD_ARG;
+    if (alg == ALG_MOD && !in2) return ECFFT_ERR_BAD_ARG;
+    if (alg == ALG_DEGREE && !degree) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(len)) return ECFFT_ERR_NOT_POW2;
+    if (count == 0) return ECFFT_ERR_BAD_ARG;
+    size_t need = (alg == ALG_MEXTEND || alg == ALG_VANISH) ? 2 * len : len;
+    if (need > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
+    if ((alg == ALG_MEXTEND || alg == ALG_REDC) && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
+    if (mem != ECFFT_MEM_HOST && mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    if ((alg == ALG_REDC || alg == ALG_MOD) && len < 2) {   // size-1 tree has no moieties: the reference would index out of bounds
+        return ECFFT_ERR_BAD_ARG;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> guard(ch.lock());
+    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
+    size_t n_in = len * count, n_out = (alg == ALG_VANISH ? 2 * len : len) * count;
+    const E *d0 = (const E*)in0, *d1 = (const E*)in1, *d2 = (const E*)in2; E* dout = (E*)out;
+    std::vector<void*> owned;
+    auto stage_in = [&](const void* h, size_t n, const E** d) -> bool {
+        if (!h || mem == ECFFT_MEM_DEVICE) return true;
+        void* p = nullptr; if (hipMalloc(&p, n * sizeof(E)) != hipSuccess) return false;
+        owned.push_back(p);
+        if (hipMemcpyAsync(p, h, n * sizeof(E), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+        *d = (const E*)p; return true;
+    };
+    bool ok = stage_in(in0, n_in, &d0) && stage_in(in1, len, &d1) && stage_in(in2, len, &d2);
+    if (ok && mem == ECFFT_MEM_HOST && alg != ALG_DEGREE) {
+        void* p = nullptr; ok = hipMalloc(&p, n_out * sizeof(E)) == hipSuccess; if (ok) { owned.push_back(p); dout = (E*)p; }
+    }
+    if (ok) {
+        switch (alg) {
+            case ALG_MEXTEND: ok = ch.api_mextend(d0, dout, len, count, moiety, s); break;
+            case ALG_REDC: ok = ch.api_redc(d0, d1, dout, len, moiety, s); break;
+            case ALG_MOD: ok = ch.api_modular_reduce(d0, d1, d2, dout, len, s); break;
+            case ALG_VANISH: ok = ch.api_vanish(d0, dout, len, s); break;
+            case ALG_DEGREE: ok = ch.api_degree(d0, len, s, degree); break;
+        }
+    }
+    if (ok && mem == ECFFT_MEM_HOST && alg != ALG_DEGREE)
+        ok = hipMemcpyAsync(out, dout, n_out * sizeof(E), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)op_end(c, s);
+    (void)hipStreamSynchronize(s);
+    for (void* p : owned) (void)hipFree(p);
+    return ok ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+#define ECFFT_DISPATCH_ALG(...) (ctx->field == ECFFT_FIELD_SECP256K1 ? run_alg(ctx, *ctx->secp, __VA_ARGS__) : run_alg(ctx, *ctx->m31, __VA_ARGS__))
 
 extern "C" {
 
@@ -306,6 +377,27 @@ int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, un
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, 0, 2, mem, stream)
                                                : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, 0, 2, mem, stream);
+}
+
+int ecfft_mextend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ECFFT_DISPATCH_ALG(ALG_MEXTEND, in, nullptr, nullptr, out, e, count, moiety, mem, stream, nullptr);
+}
+int ecfft_redc(ecfft_ctx* ctx, const void* evals, const void* a, void* out, size_t n, int moiety, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ECFFT_DISPATCH_ALG(ALG_REDC, evals, a, nullptr, out, n, 1, moiety, mem, stream, nullptr);
+}
+int ecfft_modular_reduce(ecfft_ctx* ctx, const void* evals, const void* a, const void* c, void* out, size_t n, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ECFFT_DISPATCH_ALG(ALG_MOD, evals, a, c, out, n, 1, 0, mem, stream, nullptr);
+}
+int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ECFFT_DISPATCH_ALG(ALG_VANISH, domain, nullptr, nullptr, out, nd, 1, 0, mem, stream, nullptr);
+}
+int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree);
 }
 
 int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {

@@ -27,7 +27,8 @@ TBL_F, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV
 EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_ctx_destroy", "ecfft_tree_size",
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
-           "ecfft_extend_top_cyclic", "ecfft_extend_local_block"]
+           "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
+           "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -72,6 +73,11 @@ def lib():
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+        L.ecfft_mextend.restype, L.ecfft_mextend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
+        L.ecfft_redc.restype, L.ecfft_redc.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, vp]
+        L.ecfft_modular_reduce.restype, L.ecfft_modular_reduce.argtypes = ci, [vp, vp, vp, vp, vp, sz, ci, vp]
+        L.ecfft_vanish.restype, L.ecfft_vanish.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+        L.ecfft_degree.restype, L.ecfft_degree.argtypes = ci, [vp, vp, sz, ci, vp, ctypes.POINTER(sz)]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
         L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
         L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
@@ -193,6 +199,50 @@ class FFTree:
         assert total % count == 0
         _check(lib().ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
         return out
+
+    # ---- the remaining FFTree algorithms (host numpy arrays; synchronous) ---------------------
+    def _np(self, x):
+        return np.ascontiguousarray(x, self.field.dtype)
+
+    def mextend(self, evals, moiety):
+        """src/fftree.rs:138-141"""
+        a = self._np(evals); out = np.empty_like(a)
+        _check(lib().ecfft_mextend(self._h, a.ctypes.data, out.ctypes.data, a.shape[0], int(moiety), 1, MEM_HOST, None))
+        return out
+
+    def redc_z0(self, evals, a):
+        """src/fftree.rs:264-267"""
+        return self._redc(evals, a, Moiety.S0)
+
+    def redc_z1(self, evals, a):
+        """src/fftree.rs:272-275"""
+        return self._redc(evals, a, Moiety.S1)
+
+    def _redc(self, evals, a, moiety):
+        e = self._np(evals); a = self._np(a); out = np.empty_like(e)
+        assert a.shape[0] == e.shape[0]
+        _check(lib().ecfft_redc(self._h, e.ctypes.data, a.ctypes.data, out.ctypes.data, e.shape[0], int(moiety), MEM_HOST, None))
+        return out
+
+    def modular_reduce(self, evals, a, c):
+        """src/fftree.rs:286-289"""
+        e = self._np(evals); a = self._np(a); c = self._np(c); out = np.empty_like(e)
+        assert a.shape[0] == e.shape[0] == c.shape[0]
+        _check(lib().ecfft_modular_reduce(self._h, e.ctypes.data, a.ctypes.data, c.ctypes.data, out.ctypes.data, e.shape[0], MEM_HOST, None))
+        return out
+
+    def vanish(self, domain):
+        """src/fftree.rs:313-316"""
+        d = self._np(domain)
+        out = np.empty(self.field.shape(2 * d.shape[0]), self.field.dtype)
+        _check(lib().ecfft_vanish(self._h, d.ctypes.data, out.ctypes.data, d.shape[0], MEM_HOST, None))
+        return out
+
+    def degree(self, evals):
+        """src/fftree.rs:195-198"""
+        e = self._np(evals); deg = ctypes.c_size_t()
+        _check(lib().ecfft_degree(self._h, e.ctypes.data, e.shape[0], MEM_HOST, None, ctypes.byref(deg)))
+        return deg.value
 
     # ---- shards of one EXTEND split over P GPUs (in place; see ecfft_amd/distributed.py) -----
     def _inplace(self, x):

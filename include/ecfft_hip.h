@@ -26,7 +26,8 @@
  * There is no CPU fallback: without a usable HIP device every call fails with ECFFT_ERR_HIP.
  *
  * Threading: a context is immutable after creation (like &FFTree); transform calls on one context
- * serialise on its scratch buffers; use one context per host thread/stream for concurrency.
+ * serialise on its scratch buffers (a host mutex orders the enqueues, a HIP event orders the device
+ * work across streams); use one context per host thread/stream for concurrency.
  * Ownership: the caller owns every buffer; `stream` is a hipStream_t passed as void* (NULL = default).
  */
 #ifndef ECFFT_HIP_H
@@ -81,6 +82,18 @@ int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int me
 /* `count` vectors of `e` evaluations on the moiety opposite to `moiety` -> evaluations on `moiety`
  * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend). */
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);
+
+/* The remaining FFTree algorithms, composed from the same GPU kernels.  Synchronous.
+ *   ecfft_mextend         <-> FFTree::mextend(&self, &[F], Moiety)      src/fftree.rs:138-141
+ *   ecfft_redc            <-> FFTree::redc_z0 / redc_z1(&self, evals, a)  src/fftree.rs:264-275  (moiety S0 / S1)
+ *   ecfft_modular_reduce  <-> FFTree::modular_reduce(&self, evals, a, c)  src/fftree.rs:286-289
+ *   ecfft_vanish          <-> FFTree::vanish(&self, domain) -> 2*nd evals  src/fftree.rs:313-316
+ *   ecfft_degree          <-> FFTree::degree(&self, evals) -> usize        src/fftree.rs:195-198 */
+int ecfft_mextend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);
+int ecfft_redc(ecfft_ctx* ctx, const void* evals, const void* a, void* out, size_t n, int moiety, int mem, void* stream);
+int ecfft_modular_reduce(ecfft_ctx* ctx, const void* evals, const void* a, const void* c, void* out, size_t n, int mem, void* stream);
+int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int mem, void* stream);
+int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree);
 
 /* Building blocks of ONE EXTEND of e evaluations (tree T_{2e}) split over P = 2^log_p GPUs; the
  * orchestration (RCCL all-to-all between the block and the cyclic distribution) lives above the ABI,
