@@ -403,6 +403,38 @@ public:
         return finish_api(s);
     }
 
+    // The reference's own (un-normalised) matrices of T_m, rebuilt on demand for export (src/fftree.rs:341-363):
+    // R = [[v0, s0 v0], [v1, s1 v1]], v_j = v(s_j)^(d/2-1), D = R^-1; identity where d == 1.  out: 4*m elements on the
+    // device, row-major Mat2x2 in BinaryTree heap order, crate representation.  Synchronous.
+    bool export_matrices(unsigned log_m, bool decompose, E* out, hipStream_t s) {
+        size_t m = (size_t)1 << log_m, N = N_, stride = N_ / m;
+        const E* f = f_; const E* den = den_;
+        foreach_n(s, m, [=] __device__(size_t idx) {
+            E one = F::to_mont(F::one()), zero = F::zero();
+            E r00 = one, r01 = zero, r10 = zero, r11 = one;
+            size_t d = 1; unsigned k = 0;
+            if (idx >= 2) {                                   // layer k occupies [d, 2d), d = m >> (k+1)
+                unsigned lg = 63 - __clzll((unsigned long long)idx);
+                d = (size_t)1 << lg; k = (unsigned)(__ffsll((unsigned long long)m) - 1) - 1 - lg;
+            }
+            if (idx >= 2 && d >= 2) {
+                size_t j = idx - d, lay = N >> k;
+                E s0 = f[lay + j * stride], s1 = f[lay + (j + d) * stride];
+                uint64_t ex = d / 2 - 1;
+                E v0 = F::pow_u64(F::mul_add(den[2 * k + 1], s0, den[2 * k]), ex);
+                E v1 = F::pow_u64(F::mul_add(den[2 * k + 1], s1, den[2 * k]), ex);
+                E a = v0, b = F::mul(s0, v0), c = v1, dd = F::mul(s1, v1);
+                if (decompose) {
+                    E di = F::inv(F::sub(F::mul(a, dd), F::mul(b, c)));
+                    r00 = F::mul(dd, di); r01 = F::mul(F::neg(b), di); r10 = F::mul(F::neg(c), di); r11 = F::mul(a, di);
+                } else { r00 = a; r01 = b; r10 = c; r11 = dd; }
+                r00 = F::to_mont(r00); r01 = F::to_mont(r01); r10 = F::to_mont(r10); r11 = F::to_mont(r11);
+            }
+            out[4 * idx] = r00; out[4 * idx + 1] = r01; out[4 * idx + 2] = r10; out[4 * idx + 3] = r11;
+        });
+        return hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+
     E* scratch() const { return scratch_; }
 
 private:

@@ -106,7 +106,7 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
 }
 
 template <class F>
-int table_of(const DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap, size_t* count) {
+int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap, size_t* count) {
     using E = typename F::elem;
     if (!is_pow2(m)) return ECFFT_ERR_NOT_POW2;
     if (m > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
@@ -123,12 +123,22 @@ int table_of(const DeviceChain<F>& ch, size_t m, int which, void* host_out, size
         case ECFFT_TBL_Z0Z0_REM_XNN_S: src = T.z0z0; cnt = m; break;
         case ECFFT_TBL_Z1Z1_REM_XNN_S: src = T.z1z1; cnt = m; break;
         case ECFFT_TBL_F: cnt = 2 * m; break;
+        case ECFFT_TBL_RECOMBINE: case ECFFT_TBL_DECOMPOSE: cnt = 4 * m; break;
         default: return ECFFT_ERR_BAD_ARG;
     }
     if (count) *count = cnt;
     if (!host_out) return ECFFT_OK;
     if (cap < cnt) return ECFFT_ERR_BAD_ARG;
     E* o = (E*)host_out;
+    if (which == ECFFT_TBL_RECOMBINE || which == ECFFT_TBL_DECOMPOSE) {
+        std::lock_guard<std::mutex> guard(ch.lock());
+        void* d = nullptr;
+        if (hipMalloc(&d, cnt * sizeof(E)) != hipSuccess) return ECFFT_ERR_HIP;
+        bool ok = ch.export_matrices(l, which == ECFFT_TBL_DECOMPOSE, (E*)d, nullptr) &&
+                  hipMemcpy(o, d, cnt * sizeof(E), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        return ok ? ECFFT_OK : ECFFT_ERR_HIP;      // already in the crate representation
+    }
     if (which == ECFFT_TBL_F) {
         // f of T_m: every (N/m)-th element of each layer of the top tree (src/fftree.rs:471-478)
         const std::vector<E>& f = ch.host().f; size_t N = ch.size(), stride = N / m;
@@ -400,7 +410,7 @@ int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* str
     return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree);
 }
 
-int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {
+int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return ECFFT_ERR_HIP;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)

@@ -22,7 +22,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 
 OK, ERR_NOT_POW2, ERR_TREE_TOO_SMALL, ERR_TREE_TOO_LARGE, ERR_HIP, ERR_BAD_ARG = range(6)
 MEM_HOST, MEM_DEVICE = 0, 1
-TBL_F, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV_S0, TBL_Z0Z0, TBL_Z1Z1 = 0, 3, 4, 5, 6, 7, 8, 9, 10
+TBL_F, TBL_RECOMBINE, TBL_DECOMPOSE, TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_S1, TBL_Z1_S0, TBL_Z0_INV_S1, TBL_Z1_INV_S0, TBL_Z0Z0, TBL_Z1Z1 = range(11)
 
 EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_ctx_destroy", "ecfft_tree_size",
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",

@@ -55,6 +55,8 @@ enum {
 /* tables of FFTree<F> exported by ecfft_tree_table (src/fftree.rs:25-37) */
 enum {
     ECFFT_TBL_F = 0,              /* BinaryTree<F>, 2m entries, heap order          */
+    ECFFT_TBL_RECOMBINE = 1,      /* BinaryTree<Mat2x2<F>>, m matrices = 4m elements, row-major, heap order (src/fftree.rs:26) */
+    ECFFT_TBL_DECOMPOSE = 2,      /* likewise (src/fftree.rs:27); rebuilt on demand from the normalised tables */
     ECFFT_TBL_XNN_S = 3, ECFFT_TBL_XNN_S_INV = 4, ECFFT_TBL_Z0_S1 = 5, ECFFT_TBL_Z1_S0 = 6,
     ECFFT_TBL_Z0_INV_S1 = 7, ECFFT_TBL_Z1_INV_S0 = 8, ECFFT_TBL_Z0Z0_REM_XNN_S = 9, ECFFT_TBL_Z1Z1_REM_XNN_S = 10
 };
@@ -110,7 +112,7 @@ int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, un
 
 /* copy one table of the subtree with m leaves into host memory (element representation above);
  * returns the number of elements through *count; cap = capacity of host_out in elements. */
-int ecfft_tree_table(const ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);
+int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);
 
 /* Host-only front end of build_fftree (src/lib.rs:66-81) + the layer fill of FFTree::new
  * (src/fftree.rs:49-67): writes f (2n elements, heap order: f[n..2n) = leaves x(coset_offset + i*G))

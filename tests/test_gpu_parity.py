@@ -82,14 +82,14 @@ def test_tables_match_oracle(gpu, gpu_tree, oracle_tree, oracle_mod, field):
     F, ot = oracle_tree(field, 1 << 13)
     t = gpu_tree(field, 1 << 13)
     o = oracle_mod
-    pairs = [(gpu.TBL_F, o.T_F), (gpu.TBL_XNN_S, o.T_XNN_S), (gpu.TBL_XNN_S_INV, o.T_XNN_S_INV), (gpu.TBL_Z0_S1, o.T_Z0_S1),
+    pairs = [(gpu.TBL_F, o.T_F), (gpu.TBL_RECOMBINE, o.T_RECOMBINE), (gpu.TBL_DECOMPOSE, o.T_DECOMPOSE), (gpu.TBL_XNN_S, o.T_XNN_S), (gpu.TBL_XNN_S_INV, o.T_XNN_S_INV), (gpu.TBL_Z0_S1, o.T_Z0_S1),
              (gpu.TBL_Z1_S0, o.T_Z1_S0), (gpu.TBL_Z0_INV_S1, o.T_Z0_INV_S1), (gpu.TBL_Z1_INV_S0, o.T_Z1_INV_S0),
              (gpu.TBL_Z0Z0, o.T_Z0Z0), (gpu.TBL_Z1Z1, o.T_Z1Z1)]
     for m in (2, 4, 8, 64, 1024, 8192):
         for gw, ow in pairs:
             a, b = t.table(gw, m), ot.table(ow, m)
             if gw == gpu.TBL_F:
-                a, b = a[1:], b[1:]       # index 0 of the heap is unused
+                a, b = a[1:], b[1:]       # index 0 of the heap is unused (zero in the reference, never read)
             assert np.array_equal(a, b), (m, gw)
 
 
