@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--field", default="secp256k1", choices=["secp256k1", "m31"])
     ap.add_argument("--cpu-log-n", type=int, default=15, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
+    ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -178,6 +179,24 @@ def main():
             be, bx = b_alg(n, F.elem_bytes)
             roofline["alg_bytes_check"] = {"profiler_sum_per_step": tot_alg / args.steps, "closed_form": be + bx}
 
+    # ---- extra: batched throughput (B independent polynomials share every launch; not the headline value) -----
+    batched = None
+    if args.batch > 1 and args.steps > 0:
+        B = args.batch
+        big = torch.from_numpy(np.concatenate([view] * B)).cuda() if args.field == "m31" else torch.from_numpy(np.concatenate([view] * B, axis=0)).cuda()
+        evb = tree.enter(big, count=B); backb = tree.exit(evb, count=B)        # warm-up (also grows the scratch)
+        barrier()
+        tb0 = time.perf_counter()
+        for _ in range(args.steps):
+            evb = tree.enter(big, count=B); backb = tree.exit(evb, count=B)
+        barrier()
+        tb = time.perf_counter() - tb0
+        assert torch.equal(backb, big), "batched EXIT(ENTER(c)) != c"
+        we_, wx_ = w_mul(n)
+        batched = {"batch": B, "ms_per_step": tb * 1e3 / args.steps, "ms_per_transform_pair": tb * 1e3 / args.steps / B,
+                   "field_mul_per_s_per_gpu": (we_ + wx_) * B * args.steps / tb}
+        del big, evb, backb
+
     if rank == 0:
         we, wx = w_mul(n)
         value = (we + wx) * args.steps * world / elapsed
@@ -192,6 +211,7 @@ def main():
                        "inputs": "device-resident (HBM) before the timed region", "tree_build_s": build_s},
             "roofline": roofline,
             "cpu_baseline": None,
+            "batched": batched,
         }
         out.update(split)
         if world == 1 and args.cpu_log_n > 0:

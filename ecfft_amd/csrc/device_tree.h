@@ -117,8 +117,8 @@ public:
         for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
         den_ = take(2 * (L_ ? L_ : 1));
         ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
-        // transform scratch: 4 N
-        ECFFT_HIP_TRY(hipMalloc(&scratch_, 4 * N_ * sizeof(E)));
+        // transform scratch: 4 N (grown on demand for batched calls)
+        if (!ensure_scratch(N_)) return false;
         trees_.assign(L_ + 1, Tree{});
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
@@ -257,17 +257,21 @@ public:
 
     // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.
     // in/out: device pointers, n elements, may alias.  Uses ctx scratch (caller holds lock()).
-    void enter(const E* in, E* out, size_t n, hipStream_t s) const {
-        if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, sizeof(E), hipMemcpyDeviceToDevice, s); return; }
-        E* bufA = scratch_; E* bufB = scratch_ + N_; E* work = scratch_ + 2 * N_;
+    // `count` independent polynomials of length n laid end to end share every launch (batched form; count = 1 is the
+    // reference call): level l treats the buffer as count*n/m blocks.
+    bool enter(const E* in, E* out, size_t n, size_t count, hipStream_t s) {
+        const size_t nt = n * count;
+        if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, nt * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
+        if (!ensure_scratch(nt)) return false;
+        E* bufA = scratch_; E* bufB = scratch_ + nt; E* work = scratch_ + 2 * nt;
         const E* src = in;
         unsigned ln = ilog2(n);
         unsigned l0 = 1;
         if (ln >= kLogLow) {
             // levels 1..kLogLow: one launch, one HBM round trip (k_enter_low)
             E* dst = (ln == kLogLow && out != in) ? out : bufA;
-            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += enter_level_alg_bytes(n, l);
-            ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
+            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += enter_level_alg_bytes(nt, l);
+            ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(nt >> kLogLow)), dim3(kBlockLds),
                          2 * (sizeof(E) << kLogLow), s, dst, src, (const Tree*)d_trees_);
             src = dst; l0 = kLogLow + 1;
         }
@@ -275,12 +279,13 @@ public:
             const Tree& T = trees_[l];
             size_t e = T.e;
             E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
-            { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, n, 0, s); }
-            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * n + 2.0 * e), k_enter_combine<F>, dim3(nblocks(n / 2)), dim3(kBlock), 0, s,
-                         dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), n / 2);
+            { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, nt, 0, s); }
+            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * nt + 2.0 * e), k_enter_combine<F>, dim3(nblocks(nt / 2)), dim3(kBlock), 0, s,
+                         dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), nt / 2);
             src = dst;
         }
-        if (src != out) (void)hipMemcpyAsync(out, src, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+        if (src != out) (void)hipMemcpyAsync(out, src, nt * sizeof(E), hipMemcpyDeviceToDevice, s);
+        return true;
     }
     // algorithmic bytes of one ENTER / EXIT level in the stage-streaming model
     static double enter_level_alg_bytes(size_t n, unsigned l) {
@@ -294,11 +299,13 @@ public:
     static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
-    void exit(const E* in, E* out, size_t n, hipStream_t s) const {
-        if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, sizeof(E), hipMemcpyDeviceToDevice, s); return; }
-        E* bufA = scratch_; E* bufB = scratch_ + N_; E* G = scratch_ + 2 * N_; E* H = scratch_ + 3 * N_;
+    bool exit(const E* in, E* out, size_t n1, size_t count, hipStream_t s) {
+        const size_t n = n1 * count;      // all sizes below are totals over the batch; the level count comes from n1
+        if (n1 == 1) { if (in != out) (void)hipMemcpyAsync(out, in, n * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
+        if (!ensure_scratch(n)) return false;
+        E* bufA = scratch_; E* bufB = scratch_ + n; E* G = scratch_ + 2 * n; E* H = scratch_ + 3 * n;
         const E* cur = in;
-        unsigned ln = ilog2(n);
+        unsigned ln = ilog2(n1);
         size_t nh = n / 2;
         unsigned l_stop = ln >= kLogLow ? kLogLow : 0;      // levels l_stop..1 run fused in k_exit_low
         for (unsigned l = ln; l > l_stop; --l) {
@@ -335,6 +342,7 @@ public:
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
+        return true;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -459,6 +467,13 @@ private:
         arena_ = nullptr; scratch_ = nullptr;
     }
 
+    bool ensure_scratch(size_t nt) {
+        if (scratch_cap_ >= 4 * nt) return true;
+        if (scratch_) { (void)hipDeviceSynchronize(); (void)hipFree(scratch_); scratch_ = nullptr; scratch_cap_ = 0; }
+        if (hipMalloc(&scratch_, 4 * nt * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: scratch allocation of %zu elements failed\n", 4 * nt); return false; }
+        scratch_cap_ = 4 * nt;
+        return true;
+    }
     bool finish_api(hipStream_t s) {
         bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         for (void* p : temps_) (void)hipFree(p);
@@ -716,7 +731,7 @@ private:
     E rinv_ = F::inv(F::to_mont(F::one()));   // R^-1 as a plain residue (1 for M31)
     size_t N_ = 0; unsigned L_ = 0; int device_ = 0;
     E* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
-    E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr;
+    E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr; size_t scratch_cap_ = 0;
     std::vector<Tree> trees_;
     Tree* d_trees_ = nullptr;
     std::vector<void*> temps_;

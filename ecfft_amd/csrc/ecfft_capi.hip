@@ -91,8 +91,8 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
         return ECFFT_ERR_BAD_ARG;
     }
     switch (op) {
-        case OP_ENTER: ch.enter(din, dout, len, s); break;
-        case OP_EXIT: ch.exit(din, dout, len, s); break;
+        case OP_ENTER: if (!ch.enter(din, dout, len, count, s)) return ECFFT_ERR_HIP; break;
+        case OP_EXIT: if (!ch.exit(din, dout, len, count, s)) return ECFFT_ERR_HIP; break;
         case OP_EXTEND: ch.extend(din, dout, len, count, moiety, s); break;
     }
     if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
@@ -371,6 +371,16 @@ int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int me
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream);
+}
+int ecfft_enter_many(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, size_t count, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, count, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, count, 0, mem, stream);
+}
+int ecfft_exit_many(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, size_t count, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, count, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, count, 0, mem, stream);
 }
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;

@@ -28,7 +28,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -73,6 +73,8 @@ def lib():
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+        L.ecfft_enter_many.restype, L.ecfft_enter_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
+        L.ecfft_exit_many.restype, L.ecfft_exit_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
         L.ecfft_mextend.restype, L.ecfft_mextend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
         L.ecfft_redc.restype, L.ecfft_redc.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, vp]
         L.ecfft_modular_reduce.restype, L.ecfft_modular_reduce.argtypes = ci, [vp, vp, vp, vp, vp, sz, ci, vp]
@@ -180,16 +182,19 @@ class FFTree:
         return a.ctypes.data, out, out.ctypes.data, MEM_HOST, None, a.shape[0]
 
     # ---- the path --------------------------------------------------------------------------
-    def enter(self, coeffs):
-        """coefficients -> evaluations on the leaves of T_len (src/fftree.rs:164-167)."""
+    def enter(self, coeffs, count=1):
+        """coefficients -> evaluations on the leaves of T_len (src/fftree.rs:164-167); count > 1: that many
+        polynomials laid end to end (batched form, no reference counterpart)."""
         pin, out, pout, mem, stream, n = self._io(coeffs)
-        _check(lib().ecfft_enter(self._h, pin, pout, n, mem, stream))
+        assert n % count == 0
+        _check(lib().ecfft_enter_many(self._h, pin, pout, n // count, count, mem, stream))
         return out
 
-    def exit(self, evals):
+    def exit(self, evals, count=1):
         """evaluations -> coefficients (src/fftree.rs:227-230)."""
         pin, out, pout, mem, stream, n = self._io(evals)
-        _check(lib().ecfft_exit(self._h, pin, pout, n, mem, stream))
+        assert n % count == 0
+        _check(lib().ecfft_exit_many(self._h, pin, pout, n // count, count, mem, stream))
         return out
 
     def extend(self, evals, moiety, count=1):

@@ -81,6 +81,10 @@ int ecfft_field(const ecfft_ctx* ctx);
 int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream);
 /* evaluations -> coefficients */
 int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int mem, void* stream);
+/* batched forms (no reference counterpart): `count` independent polynomials of length n, laid end to end, share every
+ * kernel launch and every table read — the throughput mode for provers that transform many columns. */
+int ecfft_enter_many(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, size_t count, int mem, void* stream);
+int ecfft_exit_many(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, size_t count, int mem, void* stream);
 /* `count` vectors of `e` evaluations on the moiety opposite to `moiety` -> evaluations on `moiety`
  * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend). */
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);

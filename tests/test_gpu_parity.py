@@ -105,6 +105,19 @@ def test_batched_extend(gpu, gpu_tree, oracle_tree, oracle_mod, field):
 
 
 @pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("n,count", [(64, 3), (2048, 5), (8192, 2)])
+def test_batched_enter_exit(gpu, gpu_tree, oracle_tree, field, n, count):
+    """count polynomials laid end to end through ecfft_enter_many / ecfft_exit_many == one at a time"""
+    F, ot = oracle_tree(field, 1 << 13)
+    t = gpu_tree(field, 1 << 13)
+    x = rand_elems(F, n * count, 41 + n)
+    ev = t.enter(x, count=count)
+    for v in range(count):
+        assert np.array_equal(ev[v * n:(v + 1) * n], ot.enter(x[v * n:(v + 1) * n]))
+    assert np.array_equal(t.exit(ev, count=count), x)
+
+
+@pytest.mark.parametrize("field", FIELDS)
 def test_fftree_new_from_leaves(gpu, oracle_tree, oracle_mod, field):
     """FFTree::new(leaves, rational_maps) (src/fftree.rs:42-70) from an externally built point set"""
     F, ot = oracle_tree(field, 64)
