@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--field", default="secp256k1", choices=["secp256k1", "m31"])
     ap.add_argument("--cpu-log-n", type=int, default=15, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
+    ap.add_argument("--mode", default="enter-exit", choices=["enter-exit", "extend-split"],
+                    help="extend-split: BASELINE configs[3] — ONE EXTEND of 2^log-n evaluations split over the ranks with RCCL all-to-all")
     ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
     args = ap.parse_args()
 
@@ -105,6 +107,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.mode == "extend-split":
+        return extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world)
 
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
@@ -221,6 +226,55 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world):
+    """BASELINE configs[3]: one EXTEND of e = 2^log_n evaluations (tree T_2e) with the evaluation domain split over the
+    ranks: block-distributed input, four RCCL all-to-alls (block<->cyclic) around the top log2(P) stages
+    (ecfft_amd/distributed.py).  Strong scaling: total work is fixed.  Checked by S0->S1->S0 round trip (identity)."""
+    from ecfft_amd import distributed as D
+    e = 1 << args.log_n
+    F = ecfft_amd.FIELDS[args.field]
+    tree = F.build_fftree(2 * e, device=local_rank)
+    c = e // world
+    host = synth(args.field, e, 0x5EED0004)[rank * c:(rank + 1) * c]          # this rank's block of the same global vector
+    x = torch.from_numpy(host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).cuda()
+
+    def run(v, moiety):
+        if world == 1:
+            return tree.extend(v, moiety)
+        return D.extend_sharded(D.HipOps(tree), v, e, moiety)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        y = run(x, ecfft_amd.Moiety.S1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = run(x, ecfft_amd.Moiety.S1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    back = run(y, ecfft_amd.Moiety.S0)
+    ok = bool(torch.equal(back, x))
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        fl = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
+    if rank == 0:
+        L = args.log_n
+        print(json.dumps({"metric": f"{args.field} Fp field-mul/s, one EXTEND of 2^{L} evaluations split over {world} GPU(s)",
+                          "value": 4 * e * L * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+                          "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1} (BASELINE.json configs[3])", "e": e,
+                                     "parallelism": f"evaluation domain block-split over {world} GPU(s), 4 all_to_all_single per EXTEND" if world > 1 else "single GPU"},
+                          "round_trip_ok": ok}))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def _traffic(kernel):
