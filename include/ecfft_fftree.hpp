@@ -68,6 +68,29 @@ public:
         check(ecfft_extend(ctx_, evals.data(), out.data(), evals.size(), (int)moiety, 1, ECFFT_MEM_HOST, nullptr));
         return out;
     }
+    // the remaining algorithms (src/fftree.rs:138-141, 195-198, 264-275, 286-289, 313-316)
+    std::vector<Elem> mextend(const std::vector<Elem>& evals, Moiety moiety) const {
+        std::vector<Elem> out(evals.size());
+        check(ecfft_mextend(ctx_, evals.data(), out.data(), evals.size(), (int)moiety, 1, ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    std::vector<Elem> redc_z0(const std::vector<Elem>& evals, const std::vector<Elem>& a) const { return redc(evals, a, Moiety::S0); }
+    std::vector<Elem> redc_z1(const std::vector<Elem>& evals, const std::vector<Elem>& a) const { return redc(evals, a, Moiety::S1); }
+    std::vector<Elem> modular_reduce(const std::vector<Elem>& evals, const std::vector<Elem>& a, const std::vector<Elem>& c) const {
+        std::vector<Elem> out(evals.size());
+        check(ecfft_modular_reduce(ctx_, evals.data(), a.data(), c.data(), out.data(), evals.size(), ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    std::vector<Elem> vanish(const std::vector<Elem>& domain) const {
+        std::vector<Elem> out(2 * domain.size());
+        check(ecfft_vanish(ctx_, domain.data(), out.data(), domain.size(), ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
+    size_t degree(const std::vector<Elem>& evals) const {
+        size_t d = 0;
+        check(ecfft_degree(ctx_, evals.data(), evals.size(), ECFFT_MEM_HOST, nullptr, &d));
+        return d;
+    }
     // device-resident variants (pointers into HBM, caller's stream)
     void enter_device(const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter(ctx_, coeffs, evals, n, ECFFT_MEM_DEVICE, stream)); }
     void exit_device(const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit(ctx_, evals, coeffs, n, ECFFT_MEM_DEVICE, stream)); }
@@ -84,6 +107,11 @@ public:
     ecfft_ctx* raw() const { return ctx_; }
 
 private:
+    std::vector<Elem> redc(const std::vector<Elem>& evals, const std::vector<Elem>& a, Moiety m) const {
+        std::vector<Elem> out(evals.size());
+        check(ecfft_redc(ctx_, evals.data(), a.data(), out.data(), evals.size(), (int)m, ECFFT_MEM_HOST, nullptr));
+        return out;
+    }
     explicit FFTree(ecfft_ctx* c) : ctx_(c) {}
     ecfft_ctx* ctx_;
 };
