@@ -148,7 +148,14 @@ public:
 #define ECFFT_LOG_TILE_BYTES 15
 #endif
     static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
-    static constexpr unsigned kColStages = 5;      // max stages per column pass (rows of tile/32 elements = 1 KiB stay coalesced)
+#ifndef ECFFT_COL_STAGES
+#define ECFFT_COL_STAGES 8
+#endif
+#ifndef ECFFT_LOG_COL_TILE_BYTES
+#define ECFFT_LOG_COL_TILE_BYTES 15
+#endif
+    static constexpr unsigned kColStages = ECFFT_COL_STAGES;      // max stages per column pass (A/B on MI355X: 8 stages x 4-element rows beat 5 x 32)
+    static constexpr unsigned kLogColTileMax = (sizeof(E) == 32) ? ECFFT_LOG_COL_TILE_BYTES - 5 : ECFFT_LOG_COL_TILE_BYTES - 2;
     void extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
                      double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
@@ -163,7 +170,10 @@ public:
         struct Pass { int kind; unsigned ka, kb; };                           // kind 0 col-decompose, 1 row, 2 col-recombine
         Pass passes[2 * 8 + 1]; int np = 0;
         if (k_first > k_begin) {                                              // balanced groups of <= kColStages stages
-            unsigned ncol = k_first - k_begin, ngrp = (ncol + kColStages - 1) / kColStages;
+            unsigned log_ct0 = tz < kLogColTileMax ? tz : kLogColTileMax;
+            unsigned rmax = kColStages < log_ct0 - 2 ? kColStages : log_ct0 - 2;    // keep rows >= 4 elements (128 B)
+            if (rmax < 1) rmax = 1;
+            unsigned ncol = k_first - k_begin, ngrp = (ncol + rmax - 1) / rmax;
             unsigned k = k_begin;
             for (unsigned g = 0; g < ngrp; ++g) { unsigned sz = ncol / ngrp + (g < ncol % ngrp ? 1 : 0); passes[np++] = {0, k, k + sz - 1}; k += sz; }
         }
@@ -188,15 +198,16 @@ public:
                 ECFFT_LAUNCH(KC_ROW, bytes, k_stages_lds<F>, dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
                              ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
             } else {
-                unsigned R = P.kb - P.ka + 1, log_c = log_tile - R;
+                unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;           // column tiles may be larger than row tiles
+                unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum) + extra;
                 if (P.kind == 0)
-                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true>), dim3((unsigned)(total >> log_ct)), dim3(kBlockLds),
+                                 ((size_t)sizeof(E)) << log_ct, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
                 else
-                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false>), dim3((unsigned)(total >> log_ct)), dim3(kBlockLds),
+                                 ((size_t)sizeof(E)) << log_ct, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
             }
         }
     }

@@ -123,7 +123,7 @@ __device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, siz
 constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS-fused kernels
 
 template <class F>
-__global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::elem> io,
+__global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ np0,
                                                            const typename F::elem* __restrict__ dinv,
                                                            const typename F::elem* __restrict__ p0,
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlockLds) void k_stages_lds(IoDesc<typename F::ele
 // stage k: (r mod d)*hs + c_global with d = 2^(kb-k).
 // ---------------------------------------------------------------------------------------------
 template <class F, bool DECOMPOSE>
-__global__ __launch_bounds__(kBlockLds) void k_stages_col(IoDesc<typename F::elem> io,
+__global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ ta,   // np0 | p0
                                                            const typename F::elem* __restrict__ tb,   // dinv | p1
                                                            uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
@@ -305,7 +305,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
 
 // ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
 template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(kBlockLds, 4) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                           const LevelTables<typename F::elem>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlockLds) void k_enter_low(typename F::elem* __res
 // EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
 // DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
 template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(kBlockLds, 4) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                          const LevelTables<typename F::elem>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
