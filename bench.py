@@ -174,6 +174,8 @@ def main():
         if dom["launches"]:
             ach = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "note": "achieved = ALGORITHMIC bytes (stage-streaming model, SURVEY 8(d)) / measured launch time: an effective "
+                                "bandwidth; the fused kernel really moves `traffic` bytes per launch and is integer-VALU bound (DESIGN.md 4)",
                         "frac": ach / HBM_PEAK_GBS, "traffic": _traffic(dom["name"]),
                         "launches_per_step": dom["launches"] / args.steps,
                         "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],

@@ -7,7 +7,7 @@ TAG=$1; KERN=$2; LAST=$3; shift 3
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python bench.py --steps 3 --warmup 1 --no-profile --cpu-log-n 0 $*"
+CMD="python bench.py --steps 3 --warmup 1 --no-profile --cpu-log-n 0 --batch 0 $*"
 echo "$CMD" > $OUT/command.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 python tools/prof_summary.py $OUT/trace/trace_results.db "rocprofv3 --kernel-trace --stats -- $CMD" > $OUT/kernel_stats.md
