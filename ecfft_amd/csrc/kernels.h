@@ -122,7 +122,7 @@ __device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, siz
 #endif
 constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS-fused kernels
 
-template <class F>
+template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
 __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ np0,
                                                            const typename F::elem* __restrict__ dinv,
@@ -133,9 +133,11 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
+    if (LOG_TILE_CT > 0) log_tile = LOG_TILE_CT;
     const uint32_t T = 1u << log_tile, tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x << log_tile;
     const size_t e = (size_t)1 << log_e, emask = e - 1;
+#pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) tile[j] = io_load<F>(io, base + j, emask);
     __syncthreads();
     const uint32_t npairs = T >> 1;
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* tn = np0 + (e - 2 * (size_t)h);
         const E* td = dinv + (e - 2 * (size_t)h);
+#pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
             E a = tile[idx], b = tile[idx + h];
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
     }
     if (log_e > 0) {
         const E c0 = inner[0], c1 = inner[1];
+#pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             E a = tile[2 * g], b = tile[2 * g + 1];
             E d = F::sub(b, a);
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const E* t0 = p0 + (e - 2 * (size_t)h);
         const E* t1 = p1 + (e - 2 * (size_t)h);
+#pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
             E a = tile[idx], b = tile[idx + h];
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
         }
         __syncthreads();
     }
+#pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) io_store<F>(io, base + j, log_e, tile[j]);
 }
 
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
 // ka -> kb (large distance first), RECOMBINE kb -> ka.  Table index of the pair (row r, column c) at
 // stage k: (r mod d)*hs + c_global with d = 2^(kb-k).
 // ---------------------------------------------------------------------------------------------
-template <class F, bool DECOMPOSE>
+template <class F, bool DECOMPOSE, int LOG_TILE_CT>     // LOG_TILE_CT > 0: log2(tile elements) known at compile time
 __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ ta,   // np0 | p0
                                                            const typename F::elem* __restrict__ tb,   // dinv | p1
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
     const uint32_t R = kb - ka + 1, tid = threadIdx.x;
-    const uint32_t C = 1u << log_c, T = C << R;
+    const uint32_t C = 1u << log_c, T = LOG_TILE_CT > 0 ? (1u << LOG_TILE_CT) : (C << R);
     const size_t e = (size_t)1 << log_e, emask = e - 1;
     const uint32_t log_hs = log_e - kb - 1;
     const size_t hs = (size_t)1 << log_hs;
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
     const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t B = (blk << (log_hs + R)) + (chunk << log_c);       // position of (row 0, col 0)
     const size_t c0 = (chunk << log_c);                              // column offset inside the hs-block
+#pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         tile[j] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
         const size_t h = hs << s;
         const E* pa = ta + (e - 2 * h);
         const E* pb = tb + (e - 2 * h);
+#pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             uint32_t cc = g & (C - 1), pr = g >> log_c;
             uint32_t r = ((pr >> s) << (s + 1)) | (pr & (d - 1));
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
         }
         __syncthreads();
     }
+#pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[j]);

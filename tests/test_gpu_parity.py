@@ -196,3 +196,36 @@ def test_full_size_properties(gpu, gpu_tree, oracle_mod, field, log_n):
     el = t.enter(lo)
     assert np.array_equal(t.extend(el[0::2].copy(), gpu.Moiety.S1), el[1::2])
     assert np.array_equal(t.extend(el[1::2].copy(), gpu.Moiety.S0), el[0::2])
+
+
+def test_one_context_from_two_threads_and_streams(gpu, gpu_tree, oracle_tree):
+    """a context serialises its transforms: two host threads driving the SAME context on different torch streams must
+    not corrupt each other's scratch (host mutex for the enqueues + HIP event across streams, ecfft_hip.h 'Threading')"""
+    import threading
+    import torch
+    F, ot = oracle_tree("secp256k1", 1 << 13)
+    t = gpu_tree("secp256k1", 1 << 13)
+    xs = [rand_elems(F, 8192, 900 + i) for i in range(2)]
+    want = [ot.enter(x) for x in xs]
+    got = [None, None]
+    errs = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d = torch.from_numpy(xs[i].view(np.int64)).cuda()
+                for _ in range(20):
+                    ev = t.enter(d)
+                    back = t.exit(ev)
+                st.synchronize()
+                got[i] = (ev.cpu().numpy().view(np.uint64), back.cpu().numpy().view(np.uint64))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(got[i][0], want[i]) and np.array_equal(got[i][1], xs[i])
