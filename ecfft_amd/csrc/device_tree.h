@@ -461,6 +461,37 @@ public:
         return hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
 
+    // out[i] = f(x[i], y[i], T[t_off + i*t_stride]) with T one of the reference's plain tables of T_m (data x
+    // plain table needs no Montgomery correction).  mode 0: x*T   1: x*T + y   2: y - x*T   3: (y - x)*T.
+    // The pointwise steps of the multi-GPU ENTER / EXIT (ecfft_amd/distributed.py) are built from this.
+    bool table_fma(E* out, const E* x, const E* y, size_t cnt, unsigned log_m, int which, size_t t_off, size_t t_stride, int mode, hipStream_t s) const {
+        const Tree& T = trees_[log_m];
+        const E* tbl = nullptr; size_t len = 0;
+        switch (which) {
+            case 3: tbl = T.xnn; len = T.m; break;           // ECFFT_TBL_XNN_S
+            case 4: tbl = T.xnn_inv; len = T.m; break;
+            case 5: tbl = T.z0_s1; len = T.e; break;
+            case 6: tbl = T.z1_s0; len = T.e; break;
+            case 7: tbl = T.z0_inv_s1; len = T.e; break;
+            case 8: tbl = T.z1_inv_s0; len = T.e; break;
+            case 9: tbl = T.z0z0; len = T.m; break;
+            case 10: tbl = T.z1z1; len = T.m; break;
+            default: return false;
+        }
+        if (cnt && t_off + (cnt - 1) * t_stride >= len) return false;
+        if (mode < 0 || mode > 3 || (mode != 0 && !y)) return false;
+        foreach_n(s, cnt, [=] __device__(size_t i) {
+            E t = tbl[t_off + i * t_stride];
+            E r;
+            if (mode == 0) r = F::mul(t, x[i]);
+            else if (mode == 1) r = F::mul_add(t, x[i], y[i]);
+            else if (mode == 2) r = F::sub(y[i], F::mul(t, x[i]));
+            else r = F::mul(t, F::sub(y[i], x[i]));
+            out[i] = r;
+        });
+        return hipGetLastError() == hipSuccess;
+    }
+
     E* scratch() const { return scratch_; }
 
 private:

@@ -246,6 +246,37 @@ int run_alg(ecfft_ctx* c, DeviceChain<F>& ch, Alg alg, const void* in0, const vo
 }
 #define ECFFT_DISPATCH_ALG(...) (ctx->field == ECFFT_FIELD_SECP256K1 ? run_alg(ctx, *ctx->secp, __VA_ARGS__) : run_alg(ctx, *ctx->m31, __VA_ARGS__))
 
+namespace {
+template <class F>
+int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
+                  size_t t_stride, int mode, int mem, void* stream) {
+    using E = typename F::elem;
+    if (!out || !x) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(m)) return ECFFT_ERR_NOT_POW2;
+    if (m > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
+    if (cnt == 0) return ECFFT_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> guard(ch.lock());
+    const E *dx = (const E*)x, *dy = (const E*)y; E* dout = (E*)out;
+    size_t bytes = cnt * sizeof(E);
+    if (mem == ECFFT_MEM_HOST) {
+        if (!ensure_stage(c, 3 * bytes)) return ECFFT_ERR_HIP;
+        E* st = (E*)c->stage;
+        if (hipMemcpyAsync(st, x, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP;
+        dx = st;
+        if (y) { if (hipMemcpyAsync(st + cnt, y, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP; dy = st + cnt; }
+        dout = st + 2 * cnt;
+    } else if (mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    if (!ch.table_fma(dout, dx, dy, cnt, ilog2(m), which, t_off, t_stride, mode, s)) return ECFFT_ERR_BAD_ARG;
+    if (mem == ECFFT_MEM_HOST) {
+        if (hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
+        if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
+    }
+    return ECFFT_OK;
+}
+}  // namespace
+
 extern "C" {
 
 size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
@@ -418,6 +449,13 @@ int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int m
 int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree);
+}
+
+int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
+                    size_t t_stride, int mode, int mem, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_table_fma(ctx, *ctx->secp, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream)
+                                               : run_table_fma(ctx, *ctx->m31, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream);
 }
 
 int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {

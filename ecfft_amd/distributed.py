@@ -22,11 +22,27 @@ import torch
 import torch.distributed as dist
 
 
+TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_INV_S1, TBL_Z0Z0 = 3, 4, 7, 9      # ECFFT_TBL_* ids (include/ecfft_hip.h)
+S0, S1 = 0, 1
+
+
 class HipOps:
-    """local stages through the C-ABI (device tensors, current stream)"""
+    """local work through the C-ABI (device tensors, current stream)"""
 
     def __init__(self, tree):
         self.tree = tree
+
+    def enter_local(self, x):
+        return self.tree.enter(x)
+
+    def exit_local(self, x):
+        return self.tree.exit(x)
+
+    def extend_local(self, x, moiety):
+        return self.tree.extend(x, moiety)
+
+    def table_fma(self, x, y, m, which, t_off, t_stride, mode):
+        return self.tree.table_fma(x, y, m, which, t_off, t_stride, mode)
 
     def top_cyclic(self, shard, e, moiety, log_p, rank, recombine):
         self.tree.extend_top_cyclic(shard, e, moiety, log_p, rank, recombine)
@@ -79,4 +95,117 @@ def extend_sharded(ops, x_block, e, moiety, group=None):
     y = block_to_cyclic(z, world, group)
     ops.top_cyclic(y, e, moiety, log_p, rank, True)
     out = cyclic_to_block(y, world, group)
+    return out.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ONE ENTER / EXIT of n coefficients split over the P ranks.
+# Block distribution: rank r holds positions [r*c, (r+1)*c), c = n/P, of the coefficient / evaluation vector.
+#   * levels with block size m <= c touch one rank only: they are the local ENTER / EXIT of the rank's chunk;
+#   * level m = c*2^j (j = 1..log2 P) works inside groups of Q = 2^j consecutive ranks: its EXTENDs are split-EXTENDs over
+#     (half-)groups, its pointwise steps are `table_fma` calls on index ranges, and one all_to_all_single with split sizes
+#     per level re-blocks the result (ENTER: interleave of S0/S1 halves; EXIT: [u0 | v0] concatenation).
+# ------------------------------------------------------------------------------------------------------------------
+def make_groups():
+    """every group of 2^j consecutive ranks, j >= 1 (collective: all ranks call it once, in the same order)"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    groups = {}
+    size = 2
+    while size <= world:
+        for idx in range(world // size):
+            g = dist.new_group(list(range(idx * size, (idx + 1) * size)))
+            if idx == rank // size:
+                groups[size] = g
+        size *= 2
+    return groups
+
+
+def _extend(ops, x, e, moiety, group):
+    if group is None or dist.get_world_size(group) == 1:
+        return ops.extend_local(x, moiety)
+    return extend_sharded(ops, x, e, moiety, group)
+
+
+def _a2a_split(pieces, dests, srcs, piece_len, Q, like, group):
+    """send pieces[k] (1-D, equal length piece_len words) to group rank dests[k] (ascending); receive one piece from each of srcs"""
+    in_split = [0] * Q
+    for d in dests:
+        in_split[d] += piece_len
+    out_split = [0] * Q
+    for s_ in srcs:
+        out_split[s_] += piece_len
+    send = torch.cat(pieces).contiguous()
+    recv = torch.empty(piece_len * len(srcs), dtype=like.dtype, device=like.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    return [recv[k * piece_len:(k + 1) * piece_len] for k in range(len(srcs))]
+
+
+def enter_sharded(ops, x_block, n, groups):
+    """FFTree::enter (src/fftree.rs:164-167) of n coefficients held block-distributed; returns this rank's block of
+    the evaluations (leaf order)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    c = x_block.shape[0]
+    assert c * world == n
+    shape = x_block.shape
+    cur = ops.enter_local(x_block.reshape(c, -1))
+    limbs = cur.shape[1]
+    Q = 2
+    while Q <= world:
+        half = Q // 2
+        base = (rank // Q) * Q
+        a = rank - base
+        m, e = c * Q, c * Q // 2
+        ext = _extend(ops, cur, e, S1, groups.get(half) if half > 1 else None)       # u1 (first half-group) or v1 (second)
+        a2 = a % half                                                                 # which chunk of u / v this rank holds
+        hc = c // 2
+        pieces = [torch.cat([cur[h * hc:(h + 1) * hc].reshape(-1), ext[h * hc:(h + 1) * hc].reshape(-1)]) for h in (0, 1)]
+        ap, b = a // 2, a % 2
+        got = _a2a_split(pieces, [2 * a2, 2 * a2 + 1], [ap, half + ap], 2 * hc * limbs, Q, cur, groups[Q])
+        u0h, u1h = got[0][:hc * limbs].reshape(hc, limbs), got[0][hc * limbs:].reshape(hc, limbs)
+        v0h, v1h = got[1][:hc * limbs].reshape(hc, limbs), got[1][hc * limbs:].reshape(hc, limbs)
+        i0 = ap * c + b * hc                                                          # first pair index of this rank's output
+        even = ops.table_fma(v0h.contiguous(), u0h.contiguous(), m, TBL_XNN_S, 2 * i0, 2, 1)        # u0 + x[2i]   * v0  (:157)
+        odd = ops.table_fma(v1h.contiguous(), u1h.contiguous(), m, TBL_XNN_S, 2 * i0 + 1, 2, 1)     # u1 + x[2i+1] * v1  (:158)
+        cur = torch.stack([even.reshape(hc, limbs), odd.reshape(hc, limbs)], dim=1).reshape(c, limbs).contiguous()
+        Q *= 2
+    return cur.reshape(shape)
+
+
+def exit_sharded(ops, y_block, n, groups):
+    """FFTree::exit (src/fftree.rs:227-230) of n evaluations held block-distributed; returns this rank's block of the
+    coefficients."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    c = y_block.shape[0]
+    assert c * world == n
+    shape = y_block.shape
+    cur = y_block.reshape(c, -1).contiguous()
+    limbs = cur.shape[1]
+    Q = world
+    while Q >= 2:
+        half = Q // 2
+        base = (rank // Q) * Q
+        a = rank - base
+        m, e = c * Q, c * Q // 2
+        G = groups[Q]
+        hc = c // 2
+        i0 = a * hc                                            # this rank holds pairs i0 .. i0 + c/2 of its block
+        e0, e1 = cur[0::2].contiguous(), cur[1::2].contiguous()
+
+        def redc(x0, x1):                                      # redc_impl with a = xnn_s, moiety S0 (:232-259)
+            t0 = ops.table_fma(x0, None, m, TBL_XNN_S_INV, 2 * i0, 2, 0)
+            g1 = _extend(ops, t0, e, S1, G)
+            h1 = ops.table_fma(ops.table_fma(g1, x1, m, TBL_XNN_S, 2 * i0 + 1, 2, 2), None, m, TBL_Z0_INV_S1, i0, 1, 0)
+            h0 = _extend(ops, h1, e, S0, G)
+            return h0, h1
+        h0, h1 = redc(e0, e1)                                  # modular_reduce_impl (:277-281)
+        hc0 = ops.table_fma(h0, None, m, TBL_Z0Z0, 2 * i0, 2, 0)
+        hc1 = ops.table_fma(h1, None, m, TBL_Z0Z0, 2 * i0 + 1, 2, 0)
+        u0, _ = redc(hc0, hc1)
+        v0 = ops.table_fma(u0, e0, m, TBL_XNN_S_INV, 2 * i0, 2, 3)                    # (e0 - u0) * xinv  (:217-219)
+        # block <- [u0 | v0]: u0 part to group rank a//2, v0 part to group rank Q/2 + a//2
+        ap = a if a < half else a - half
+        got = _a2a_split([u0.reshape(-1), v0.reshape(-1)], [a // 2, half + a // 2], [2 * ap, 2 * ap + 1], hc * limbs, Q, cur, G)
+        cur = torch.cat([got[0].reshape(hc, limbs), got[1].reshape(hc, limbs)]).contiguous()
+        Q //= 2
+    out = ops.exit_local(cur)
     return out.reshape(shape)

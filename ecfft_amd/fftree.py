@@ -28,7 +28,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -73,6 +73,7 @@ def lib():
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+        L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
         L.ecfft_enter_many.restype, L.ecfft_enter_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
         L.ecfft_exit_many.restype, L.ecfft_exit_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
         L.ecfft_mextend.restype, L.ecfft_mextend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
@@ -248,6 +249,16 @@ class FFTree:
         e = self._np(evals); deg = ctypes.c_size_t()
         _check(lib().ecfft_degree(self._h, e.ctypes.data, e.shape[0], MEM_HOST, None, ctypes.byref(deg)))
         return deg.value
+
+    def table_fma(self, x, y, m, which, t_off, t_stride, mode):
+        """out[i] = f(x[i], y[i], T_m.table[which][t_off + i*t_stride]); mode 0: x*T, 1: x*T + y, 2: y - x*T, 3: (y - x)*T"""
+        pin, out, pout, mem, stream, n = self._io(x)
+        py, keep = None, None
+        if y is not None:
+            keep = y if _is_torch(y) else np.ascontiguousarray(y, self.field.dtype)     # keep the buffer alive across the call
+            py = keep.data_ptr() if _is_torch(y) else keep.ctypes.data
+        _check(lib().ecfft_table_fma(self._h, pout, pin, py, n, m, which, t_off, t_stride, mode, mem, stream))
+        return out
 
     # ---- shards of one EXTEND split over P GPUs (in place; see ecfft_amd/distributed.py) -----
     def _inplace(self, x):

@@ -114,6 +114,13 @@ int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, uns
                             int mem, void* stream);
 int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream);
 
+/* Pointwise building block of the multi-GPU ENTER / EXIT (no reference counterpart): with T = table `which` (one of
+ * ECFFT_TBL_XNN_S .. ECFFT_TBL_Z1Z1_REM_XNN_S) of the subtree with m leaves,
+ *     mode 0: out[i] = x[i]*T[j]    1: x[i]*T[j] + y[i]    2: y[i] - x[i]*T[j]    3: (y[i] - x[i])*T[j],   j = t_off + i*t_stride.
+ * These are the loops src/fftree.rs:155-159, 217-219, 238, 253-255, 279 restricted to an index range. */
+int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
+                    size_t t_stride, int mode, int mem, void* stream);
+
 /* copy one table of the subtree with m leaves into host memory (element representation above);
  * returns the number of elements through *count; cap = capacity of host_out in elements. */
 int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);

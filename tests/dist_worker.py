@@ -49,6 +49,37 @@ class OracleOps:
         x[lo] = o0
         x[lo + h_local] = o1
 
+    # --- whole local transforms and pointwise table steps (multi-GPU ENTER / EXIT) ---
+    def _np(self, t):
+        return t.contiguous().numpy().view(self.F.dtype).reshape(self.F.shape(t.shape[0]))
+
+    def _t(self, a):
+        v = np.ascontiguousarray(a).view(np.int64 if self.F.limbs > 1 else np.int32).reshape(a.shape[0], -1)
+        return torch.from_numpy(v.copy())
+
+    def enter_local(self, x):
+        return self._t(self.t.enter(self._np(x)))
+
+    def exit_local(self, x):
+        return self._t(self.t.exit(self._np(x)))
+
+    def extend_local(self, x, moiety):
+        return self._t(self.t.extend(self._np(x), moiety))
+
+    def table_fma(self, x, y, m, which, t_off, t_stride, mode):
+        F = self.F
+        xn = self._np(x)
+        T = self.t.table(which, m)[t_off + np.arange(xn.shape[0]) * t_stride]
+        if mode == 0:
+            r = F.mul(xn, T)
+        elif mode == 1:
+            r = F.add(F.mul(xn, T), self._np(y))
+        elif mode == 2:
+            r = F.sub(self._np(y), F.mul(xn, T))
+        else:
+            r = F.mul(F.sub(self._np(y), xn), T)
+        return self._t(r)
+
     def top_cyclic(self, shard, e, moiety, log_p, rank, recombine):
         x = shard.numpy().view(self.F.dtype).reshape(self.F.shape(shard.shape[0]))
         P = 1 << log_p
@@ -93,6 +124,31 @@ def main():
             ok = ok and torch.equal(back, t)
             cyc = D.block_to_cyclic(t.clone(), world).numpy().view(F.dtype).reshape(F.shape(c))
             ok = ok and np.array_equal(cyc, x[rank::world])
+    # ---- one ENTER / EXIT of n coefficients split over the ranks ----
+    groups = D.make_groups()
+    for field, n in (("m31", 256), ("secp256k1", 128), ("m31", 2048)):
+        F = oracle.field(field)
+        ot = F.build_fftree(n)
+        rng = np.random.default_rng(99)
+        if field == "m31":
+            x = rng.integers(0, 2**31 - 1, n, dtype=np.uint32)
+        else:
+            p = 2**256 - 2**32 - 977
+            x = F.from_ints([int.from_bytes(rng.bytes(32), "little") % p for _ in range(n)])
+        c = n // world
+        if c < 4 * world:
+            continue
+        ops = OracleOps(F, ot)
+        want = ot.enter(x)
+        mine = ops._t(x[rank * c:(rank + 1) * c])
+        ev = D.enter_sharded(ops, mine, n, groups)
+        ok = ok and np.array_equal(ops._np(ev), want[rank * c:(rank + 1) * c])
+        back = D.exit_sharded(ops, ev, n, groups)
+        ok = ok and np.array_equal(ops._np(back), x[rank * c:(rank + 1) * c])
+        # EXIT of arbitrary evaluations against the oracle
+        r = ot.exit(x)
+        got = D.exit_sharded(ops, mine, n, groups)
+        ok = ok and np.array_equal(ops._np(got), r[rank * c:(rank + 1) * c])
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

@@ -81,3 +81,22 @@ def test_algorithm_errors(trees, field):
         gt.vanish(rand_elems(F, 2048, 1))
     with pytest.raises(AssertionError):
         gt.degree(rand_elems(F, 24, 1))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_table_fma_building_block(trees, oracle_mod, field):
+    """ecfft_table_fma — the pointwise step of the multi-GPU ENTER / EXIT — against oracle tables and field ops"""
+    F, ot, gt, G = trees[field]
+    o = oracle_mod
+    m, cnt, off, stride = 256, 50, 7, 2
+    x, y = rand_elems(F, cnt, 1), rand_elems(F, cnt, 2)
+    for which in (o.T_XNN_S, o.T_XNN_S_INV, o.T_Z0Z0):
+        T = ot.table(which, m)[off + np.arange(cnt) * stride]
+        assert np.array_equal(gt.table_fma(x, None, m, which, off, stride, 0), F.mul(x, T))
+        assert np.array_equal(gt.table_fma(x, y, m, which, off, stride, 1), F.add(F.mul(x, T), y))
+        assert np.array_equal(gt.table_fma(x, y, m, which, off, stride, 2), F.sub(y, F.mul(x, T)))
+        assert np.array_equal(gt.table_fma(x, y, m, which, off, stride, 3), F.mul(F.sub(y, x), T))
+    T = ot.table(o.T_Z0_INV_S1, m)[3:3 + cnt]
+    assert np.array_equal(gt.table_fma(x, None, m, o.T_Z0_INV_S1, 3, 1, 0), F.mul(x, T))
+    with pytest.raises(Exception):
+        gt.table_fma(x, None, m, o.T_XNN_S, 250, 2, 0)          # index range beyond the table
