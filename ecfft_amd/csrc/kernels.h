@@ -20,8 +20,8 @@ namespace ecfft {
 constexpr int kBlock = 256;
 
 // ---------------------------------------------------------------------------------------------
-// streaming butterfly stages (one launch per stage; used for strides that do not fit one
-// workgroup's LDS tile and as the simple reference path for the fused kernels)
+// streaming butterfly stages (one launch per stage).  On the hot path only the cyclic shards of a
+// multi-GPU split EXTEND use them (log2 P stages with strided tables); everything else is fused below.
 // buf holds `npairs*2` elements = count vectors of length e laid end to end; h = pair distance.
 // ---------------------------------------------------------------------------------------------
 template <class F>
@@ -446,68 +446,6 @@ __global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __re
     typename F::elem odd = F::mul_add(w1x[i], V1, F::mul(w1[i], U1));
     dst[base + 2 * i] = even;
     dst[base + 2 * i + 1] = odd;
-}
-
-// ---------------------------------------------------------------------------------------------
-// pointwise kernels of EXIT (src/fftree.rs:200-224, 232-259, 277-281) — level m, e = m/2.
-// cur is n elements in blocks of m (leaf order of T_m); G, H are n/2-element work arrays holding
-// one length-e vector per block.
-// ---------------------------------------------------------------------------------------------
-// G[b*e+i] = cur[b*m+2i] * A1[i]                       (t0 = e0/a0, pre-normalised)
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_exit_pre1(typename F::elem* __restrict__ G,
-                                                       const typename F::elem* __restrict__ cur,
-                                                       const typename F::elem* __restrict__ A1,
-                                                       uint32_t log_e, size_t nhalf) {
-    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= nhalf) return;
-    size_t i = g & (((size_t)1 << log_e) - 1);
-    G[g] = F::mul(A1[i], cur[2 * g]);
-}
-// H[g] = G[g] = cur[2g+1]*B1[i] + G[g]*NB2[i]          (h1 of the first REDC, normalised for S1->S0)
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_exit_mid1(typename F::elem* G,
-                                                       typename F::elem* __restrict__ H,
-                                                       const typename F::elem* __restrict__ cur,
-                                                       const typename F::elem* __restrict__ B1,
-                                                       const typename F::elem* __restrict__ NB2,
-                                                       uint32_t log_e, size_t nhalf) {
-    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= nhalf) return;
-    size_t i = g & (((size_t)1 << log_e) - 1);
-    typename F::elem r = F::mul_add(NB2[i], G[g], F::mul(B1[i], cur[2 * g + 1]));
-    G[g] = r;
-    H[g] = r;
-}
-// G[g] = H[g]*D1[i] + G[g]*NB2[i]                      (h1 of the second REDC)
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_exit_mid2(typename F::elem* G,
-                                                       const typename F::elem* __restrict__ H,
-                                                       const typename F::elem* __restrict__ D1,
-                                                       const typename F::elem* __restrict__ NB2,
-                                                       uint32_t log_e, size_t nhalf) {
-    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= nhalf) return;
-    size_t i = g & (((size_t)1 << log_e) - 1);
-    G[g] = F::mul_add(NB2[i], G[g], F::mul(D1[i], H[g]));
-}
-// u0 = G*w0 ; v0 = (cur[2g] - u0)*xie ; dst block = [u0 | v0]
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_exit_split(typename F::elem* __restrict__ dst,
-                                                        const typename F::elem* __restrict__ cur,
-                                                        const typename F::elem* __restrict__ G,
-                                                        const typename F::elem* __restrict__ w0,
-                                                        const typename F::elem* __restrict__ xie,
-                                                        uint32_t log_e, size_t nhalf) {
-    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= nhalf) return;
-    size_t e = (size_t)1 << log_e;
-    size_t i = g & (e - 1);
-    size_t base = (g >> log_e) << (log_e + 1);
-    typename F::elem u0 = F::mul(w0[i], G[g]);
-    typename F::elem v0 = F::mul(xie[i], F::sub(cur[2 * g], u0));
-    dst[base + i] = u0;
-    dst[base + e + i] = v0;
 }
 
 // ---------------------------------------------------------------------------------------------
