@@ -50,6 +50,36 @@ struct Secp256k1 {
     }
     // a - b mod p
     __host__ __device__ static inline elem sub(const elem& a, const elem& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ECFFT_NO_ASM_MUL)
+        // 18 instructions: 8-word borrow chain, then subtract (borrow ? 2^32 + 977 : 0), i.e. add p modulo 2^256
+        // (hipcc lowers the portable code below to ~64 instructions)
+        uint32_t d0, d1, d2, d3, d4, d5, d6, d7, k0, k1;
+        const uint32_t c977 = C977;
+        asm("v_sub_co_u32_e32 %0, vcc, %10, %18\n\t"
+            "v_subb_co_u32_e32 %1, vcc, %11, %19, vcc\n\t"
+            "v_subb_co_u32_e32 %2, vcc, %12, %20, vcc\n\t"
+            "v_subb_co_u32_e32 %3, vcc, %13, %21, vcc\n\t"
+            "v_subb_co_u32_e32 %4, vcc, %14, %22, vcc\n\t"
+            "v_subb_co_u32_e32 %5, vcc, %15, %23, vcc\n\t"
+            "v_subb_co_u32_e32 %6, vcc, %16, %24, vcc\n\t"
+            "v_subb_co_u32_e32 %7, vcc, %17, %25, vcc\n\t"
+            "v_cndmask_b32_e64 %9, 0, 1, vcc\n\t"
+            "v_mul_u32_u24_e32 %8, %26, %9\n\t"
+            "v_sub_co_u32_e32 %0, vcc, %0, %8\n\t"
+            "v_subb_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+            "v_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+            "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+            "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+            "v_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+            "v_subbrev_co_u32_e32 %7, vcc, 0, %7, vcc"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&v"(k0), "=&v"(k1)
+            : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]),
+              "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "s"(c977)
+            : "vcc");
+        elem r; r.l[0] = d0; r.l[1] = d1; r.l[2] = d2; r.l[3] = d3; r.l[4] = d4; r.l[5] = d5; r.l[6] = d6; r.l[7] = d7;
+        return r;
+#else
         uint32_t d[8]; int64_t bw = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { int64_t t = (int64_t)a.l[i] - b.l[i] + bw; d[i] = (uint32_t)t; bw = t >> 32; }
@@ -62,6 +92,7 @@ struct Secp256k1 {
             int64_t t = (int64_t)d[i] - (i == 0 ? k0 : (i == 1 ? k1 : 0u)) + c2; r.l[i] = (uint32_t)t; c2 = t >> 32;
         }
         return r;
+#endif
     }
     __host__ __device__ static inline elem neg(const elem& a) { return sub(zero(), a); }
 
