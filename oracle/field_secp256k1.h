@@ -87,9 +87,37 @@ static inline fe fe_pow_limbs(fe a, const uint64_t e[4]) {
     for (int i = 255; i >= 0; --i) { r = fe_sqr(r); if ((e[i / 64] >> (i % 64)) & 1) r = fe_mul(r, a); }
     return r;
 }
-static inline fe fe_inv(fe a) { /* a^(p-2); a != 0 */
-    static const uint64_t e[4] = {0xFFFFFFFEFFFFFC2DULL, ~0ULL, ~0ULL, ~0ULL};
-    return fe_pow_limbs(a, e);
+/* ark-ff 0.4 `Fp::inverse` for Montgomery elements: binary extended Euclid (Guajardo, Kumar, Paar, Pelzl, Algorithm 16)
+ * on the raw limbs with b starting at R^2, so that (aR) -> a^-1 R.  Kept close to the crate's cost (a few microseconds)
+ * because the reference's REDC inverts on every call (src/fftree.rs:235) and this file is also the CPU baseline. */
+static inline int u256_is_one(const uint64_t x[4]) { return x[0] == 1 && (x[1] | x[2] | x[3]) == 0; }
+static inline int u256_lt(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; --i) { if (a[i] < b[i]) return 1; if (a[i] > b[i]) return 0; }
+    return 0;
+}
+static inline void u256_sub(uint64_t a[4], const uint64_t b[4]) {
+    u128 bw = 0;
+    for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - b[i] - (uint64_t)bw; a[i] = (uint64_t)d; bw = (d >> 64) & 1; }
+}
+static inline void u256_shr1(uint64_t a[4], uint64_t top) {
+    a[0] = (a[0] >> 1) | (a[1] << 63); a[1] = (a[1] >> 1) | (a[2] << 63); a[2] = (a[2] >> 1) | (a[3] << 63); a[3] = (a[3] >> 1) | (top << 63);
+}
+static inline void fe_half(fe* b) { /* b/2 mod p */
+    uint64_t carry = 0;
+    if (b->l[0] & 1) { u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)b->l[i] + FE_P[i]; b->l[i] = (uint64_t)c; c >>= 64; } carry = (uint64_t)c; }
+    u256_shr1(b->l, carry);
+}
+static inline fe fe_inv(fe a) { /* a != 0 */
+    uint64_t u[4], v[4];
+    memcpy(u, a.l, 32); memcpy(v, FE_P, 32);
+    fe b = FE_R2, c = fe_zero();
+    while (!u256_is_one(u) && !u256_is_one(v)) {
+        while (!(u[0] & 1)) { u256_shr1(u, 0); fe_half(&b); }
+        while (!(v[0] & 1)) { u256_shr1(v, 0); fe_half(&c); }
+        if (u256_lt(v, u)) { u256_sub(u, v); b = fe_sub(b, c); }
+        else { u256_sub(v, u); c = fe_sub(c, b); }
+    }
+    return u256_is_one(u) ? b : c;
 }
 /* ark-ff sqrt for p = 3 mod 4: candidate a^((p+1)/4), accepted iff its square is a. returns 1 if QR */
 static inline int fe_sqrt(fe a, fe* out) {
