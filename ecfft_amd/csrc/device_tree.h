@@ -156,8 +156,14 @@ public:
 #endif
     static constexpr unsigned kColStages = ECFFT_COL_STAGES;      // max stages per column pass (A/B on MI355X: 8 stages x 4-element rows beat 5 x 32)
     static constexpr unsigned kLogColTileMax = (sizeof(E) == 32) ? ECFFT_LOG_COL_TILE_BYTES - 5 : ECFFT_LOG_COL_TILE_BYTES - 2;
-    void extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
-                     double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0) const {
+    // Fusion of consecutive cores (EXIT): `next_ld` != nullptr says that another core of the same tree and size, opposite
+    // direction, follows on `buf` with that load operator; if this core ends in a column pass, that pass and the next
+    // core's first column pass run as ONE launch (k_stages_col_mid) and the function returns true; the next core is then
+    // called with skip_first_col = true.
+    struct NextLoad { int ld_mode; const E* ld_tbl; double extra_first; };
+    bool extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
+                     double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0,
+                     const NextLoad* next_ld = nullptr, bool skip_first_col = false) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
         const Tree& T = trees_[log_m];
         size_t e = T.e; unsigned le = ilog2(e);
@@ -181,9 +187,23 @@ public:
         passes[np++] = {1, k_first, le};
         for (int g = nd - 1; g >= 0; --g) passes[np++] = {2, passes[g].ka, passes[g].kb};
         const E* plain_src = buf;
-        for (int pi = 0; pi < np; ++pi) {
+        const bool fuse_tail = next_ld && nd >= 1 && (io.st_mode == ST_PLAIN || io.st_mode == ST_SCALE || io.st_mode == ST_AXPBY) && io.dst == buf;
+        const int pi0 = (skip_first_col && nd >= 1) ? 1 : 0;
+        for (int pi = pi0; pi < np; ++pi) {
             IoDesc<E> d;
             bool first = pi == 0, last = pi == np - 1;
+            if (last && fuse_tail) {
+                // this core's last recombine group + the next core's first decompose group (same stages, same tiles)
+                const Pass& P = passes[pi];
+                d = io; d.src = buf; d.dst = buf; d.ld_mode = next_ld->ld_mode; d.ld_tbl = next_ld->ld_tbl;
+                unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;
+                unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
+                double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
+                double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum) + extra_last + next_ld->extra_first;
+                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), ((size_t)sizeof(E)) << log_ct, s,
+                             d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
+                return true;
+            }
             // load side
             if (first) { d = io; } else { d = IoDesc<E>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
             // store side
@@ -217,6 +237,7 @@ public:
                 }
             }
         }
+        return false;
     }
     static IoDesc<E> io_plain(const E* src, E* dst) {
         IoDesc<E> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;
@@ -341,15 +362,17 @@ public:
             IoDesc<E> io1 = io_plain(cur, G);
             io1.src_stride = 2; io1.src_off = 0; io1.ld_mode = LD_SCALE; io1.ld_tbl = T.A1;
             io1.st_mode = ST_AXPBY; io1.st_a = T.NB2; io1.st_b = T.B1; io1.aux = cur; io1.aux_stride = 2; io1.aux_off = 1; io1.aux_out = H;
-            extend_core(l, io1, G, nh, 0, s, se * (1.0 * n + ee), se * (1.5 * n + 2.0 * ee));
-            extend_core(l, io_plain(G, G), G, nh, 1, s);
+            // consecutive cores meet at a column pass on the same tiles: run those two passes as one launch (k_stages_col_mid)
+            NextLoad nl2{LD_PLAIN, nullptr, 0.0}, nl3{LD_SCALE, T.C1, se * (3.0 * n + 3.0 * ee)}, nl4{LD_PLAIN, nullptr, 0.0};
+            bool f1 = extend_core(l, io1, G, nh, 0, s, se * (1.0 * n + ee), se * (1.5 * n + 2.0 * ee), 0, &nl2, false);
+            bool f2 = extend_core(l, io_plain(G, G), G, nh, 1, s, 0.0, 0.0, 0, &nl3, f1);
             IoDesc<E> io3 = io_plain(G, G);
             io3.ld_mode = LD_SCALE; io3.ld_tbl = T.C1;
             io3.st_mode = ST_AXPBY; io3.st_a = T.NB2; io3.st_b = T.D1; io3.aux = H; io3.aux_stride = 1; io3.aux_off = 0; io3.aux_out = nullptr;
-            extend_core(l, io3, G, nh, 0, s, se * (3.0 * n + 3.0 * ee), se * (1.5 * n + 2.0 * ee));
+            bool f3 = extend_core(l, io3, G, nh, 0, s, f2 ? 0.0 : se * (3.0 * n + 3.0 * ee), se * (1.5 * n + 2.0 * ee), 0, &nl4, f2);
             IoDesc<E> io4 = io_plain(G, dst);
             io4.st_mode = ST_EXIT_SPLIT; io4.st_a = T.w[0]; io4.st_b = T.xie; io4.aux = cur; io4.aux_stride = 2; io4.aux_off = 0;
-            extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee));
+            extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee), 0, nullptr, f3);
             cur = dst;
         }
         if (l_stop) {

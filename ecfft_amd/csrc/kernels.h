@@ -108,6 +108,22 @@ __device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, siz
     }
 }
 
+// the store operator of one EXTEND core followed by the load operator of the next one, applied to a value in flight
+// (ST_PLAIN / ST_SCALE / ST_AXPBY only; side output aux_out is written): used where two cores are fused in one launch
+template <class F>
+__device__ __forceinline__ typename F::elem io_mid(const IoDesc<typename F::elem>& io, size_t pos, size_t emask, const typename F::elem& x) {
+    using E = typename F::elem;
+    const size_t i = pos & emask;
+    E r = x;
+    if (io.st_mode == ST_SCALE) r = F::mul(io.st_a[i], x);
+    else if (io.st_mode == ST_AXPBY) {
+        r = F::mul_add(io.st_a[i], x, F::mul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+        if (io.aux_out) io.aux_out[pos] = r;
+    }
+    if (io.ld_mode == LD_SCALE) r = F::mul(io.ld_tbl[i], r);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-fused butterfly stages, "row kernel".  One workgroup owns a contiguous tile of 2^log_tile
 // elements (<= 64 KiB of LDS: 2048 secp256k1 / 16384 M31 elements), loads it once, runs every
@@ -246,6 +262,75 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two consecutive EXTEND cores of an EXIT level meet at a column pass: core A ends with the recombine stages kb..ka,
+// core B (opposite direction, SAME point set: A's target parity = B's source parity) starts with the decompose stages
+// ka..kb on the same tiles, with only a pointwise step in between.  This kernel runs both halves on one tile residency:
+// load, R recombine stages, io_mid (A's store operator + B's load operator), R decompose stages, store — one launch and
+// one HBM round trip instead of two.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(kBlockLds, 4) void k_stages_col_mid(IoDesc<typename F::elem> io,
+                                                               const typename F::elem* __restrict__ p0, const typename F::elem* __restrict__ p1,
+                                                               const typename F::elem* __restrict__ np0, const typename F::elem* __restrict__ dinv,
+                                                               uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    E* tile = reinterpret_cast<E*>(ecfft_smem);
+    const uint32_t R = kb - ka + 1, tid = threadIdx.x;
+    const uint32_t C = 1u << log_c, T = C << R;
+    const size_t e = (size_t)1 << log_e, emask = e - 1;
+    const uint32_t log_hs = log_e - kb - 1;
+    const size_t hs = (size_t)1 << log_hs;
+    const uint32_t chunks_log = log_hs - log_c;
+    const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+    const size_t B = (blk << (log_hs + R)) + (chunk << log_c);
+    const size_t c0 = (chunk << log_c);
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        uint32_t r = j >> log_c, cc = j & (C - 1);
+        tile[j] = io.src[B + ((size_t)r << log_hs) + cc];
+    }
+    __syncthreads();
+    const uint32_t npairs = T >> 1;
+    for (uint32_t half = 0; half < 2; ++half) {
+        const bool dec = half == 1;
+        for (uint32_t st = 0; st < R; ++st) {
+            const uint32_t k = dec ? ka + st : kb - st;
+            const uint32_t sft = kb - k, d = 1u << sft;
+            const size_t h = hs << sft;
+            const E* pa = (dec ? np0 : p0) + (e - 2 * h);
+            const E* pb = (dec ? dinv : p1) + (e - 2 * h);
+            for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+                uint32_t cc = g & (C - 1), pr = g >> log_c;
+                uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
+                size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
+                uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+                E a = tile[lo], b = tile[hi];
+                if (dec) {
+                    E q1 = F::mul(pb[i], F::sub(b, a));
+                    E q0 = F::mul_add(pa[i], q1, a);
+                    tile[lo] = q0; tile[hi] = q1;
+                } else {
+                    tile[lo] = F::mul_add(pa[i], b, a);
+                    tile[hi] = F::mul_add(pb[i], b, a);
+                }
+            }
+            __syncthreads();
+        }
+        if (!dec) {
+            for (uint32_t j = tid; j < T; j += kBlockLds) {
+                uint32_t r = j >> log_c, cc = j & (C - 1);
+                tile[j] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[j]);
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        uint32_t r = j >> log_c, cc = j & (C - 1);
+        io.dst[B + ((size_t)r << log_hs) + cc] = tile[j];
     }
 }
 
