@@ -101,15 +101,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("ECFFT_BENCH_BACKEND", "nccl")      # "gloo" lets several ranks share one GPU (functional test only)
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): one process per GPU")
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     if args.mode == "extend-split":
-        return extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world)
+        return extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev)
 
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
@@ -148,7 +157,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.equal(back, coeffs), "EXIT(ENTER(c)) != c"
@@ -230,7 +239,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world):
+def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda"):
     """BASELINE configs[3]: one EXTEND of e = 2^log_n evaluations (tree T_2e) with the evaluation domain split over the
     ranks: block-distributed input, four RCCL all-to-alls (block<->cyclic) around the top log2(P) stages
     (ecfft_amd/distributed.py).  Strong scaling: total work is fixed.  Checked by S0->S1->S0 round trip (identity)."""
@@ -264,8 +273,8 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world):
     back = run(y, ecfft_amd.Moiety.S0)
     ok = bool(torch.equal(back, x))
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
-        fl = torch.tensor([1 if ok else 0], device="cuda"); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
     if rank == 0:
         L = args.log_n
         print(json.dumps({"metric": f"{args.field} Fp field-mul/s, one EXTEND of 2^{L} evaluations split over {world} GPU(s)",
