@@ -117,8 +117,10 @@ public:
         for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
         den_ = take(2 * (L_ ? L_ : 1));
         ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
-        // transform scratch: 4 N (grown on demand for batched calls)
+        // transform scratch: 5 N (grown on demand for batched calls); side stream for the two-halves schedule
         if (!ensure_scratch(N_)) return false;
+        if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess) { side_ = nullptr; }
         trees_.assign(L_ + 1, Tree{});
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
@@ -199,7 +201,7 @@ public:
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
-                double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum) + extra_last + next_ld->extra_first;
+                double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
                 ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), ((size_t)sizeof(E)) << log_ct, s,
                              d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
                 return true;
@@ -214,7 +216,7 @@ public:
             if (P.kind == 1) {
                 unsigned nst = le - k_first;
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
-                double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum) + extra;
+                double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
                 if (log_tile == kLogTileMax && sizeof(E) == 4)   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
@@ -225,7 +227,7 @@ public:
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;           // column tiles may be larger than row tiles
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
-                double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum) + extra;
+                double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
                 const bool ct = (log_ct == kLogColTileMax && sizeof(E) == 4);
                 dim3 grid((unsigned)(total >> log_ct)); size_t lds = ((size_t)sizeof(E)) << log_ct;
                 if (P.kind == 0) {
@@ -302,54 +304,93 @@ public:
         const size_t nt = n * count;
         if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, nt * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
         if (!ensure_scratch(nt)) return false;
-        E* bufA = scratch_; E* bufB = scratch_ + nt; E* work = scratch_ + 2 * nt;
-        const E* src = in;
         unsigned ln = ilog2(n);
-        unsigned l0 = 1;
-        if (ln >= kLogLow) {
+        if (count == 1 && ln >= kSplitMinLog && side_) {
+            // Two concurrent halves: levels 1..L-1 never mix the two half-blocks, so they run as two independent ENTERs of
+            // n/2 on two streams.  Their launches (each half as wide) interleave on the chip, so one half's load / store
+            // phases overlap the other's compute; only the top level runs on the whole array.
+            E* X = scratch_; E* sA = scratch_ + n; E* sB = sA + 3 * (n / 2);
+            fork(s);
+            enter_levels(in, X, n / 2, 1, s, sA, 1, ln - 1);
+            tblw_ = 0.0; enter_levels(in + n / 2, X + n / 2, n / 2, 1, side_, sB, 1, ln - 1); tblw_ = 1.0;
+            join(s);
+            enter_levels(X, out, n, 1, s, sA, ln, ln);
+        } else {
+            enter_levels(in, out, n, count, s, scratch_, 1, ln);
+        }
+        return true;
+    }
+    // levels l_begin..l_end of ENTER on count arrays of n elements; `in` = state before level l_begin; base = 3*n*count
+    // elements of scratch (ping, pong, EXTEND work)
+    void enter_levels(const E* in, E* out, size_t n, size_t count, hipStream_t s, E* base, unsigned l_begin, unsigned l_end) const {
+        const size_t nt = n * count;
+        E* bufA = base; E* bufB = base + nt; E* work = base + 2 * nt;
+        const E* src = in;
+        unsigned l0 = l_begin;
+        if (l_begin == 1 && l_end >= kLogLow) {
             // levels 1..kLogLow: one launch, one HBM round trip (k_enter_low)
-            E* dst = (ln == kLogLow && out != in) ? out : bufA;
+            E* dst = (l_end == kLogLow && out != in) ? out : bufA;
             double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += enter_level_alg_bytes(nt, l);
             ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(nt >> kLogLow)), dim3(kBlockLds),
                          2 * (sizeof(E) << kLogLow), s, dst, src, (const Tree*)d_trees_);
             src = dst; l0 = kLogLow + 1;
         }
-        for (unsigned l = l0; l <= ln; ++l) {
+        for (unsigned l = l0; l <= l_end; ++l) {
             const Tree& T = trees_[l];
             size_t e = T.e;
-            E* dst = (l == ln && out != in) ? out : (src == bufA ? bufB : bufA);
+            E* dst = (l == l_end && out != in) ? out : (src == bufA ? bufB : bufA);
             { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, nt, 0, s); }
-            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * nt + 2.0 * e), k_enter_combine<F>, dim3(nblocks(nt / 2)), dim3(kBlock), 0, s,
+            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * nt + 2.0 * e * tblw_), k_enter_combine<F>, dim3(nblocks(nt / 2)), dim3(kBlock), 0, s,
                          dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), nt / 2);
             src = dst;
         }
         if (src != out) (void)hipMemcpyAsync(out, src, nt * sizeof(E), hipMemcpyDeviceToDevice, s);
-        return true;
     }
     // algorithmic bytes of one ENTER / EXIT level in the stage-streaming model
-    static double enter_level_alg_bytes(size_t n, unsigned l) {
+    // (tblw_ = 0 while the second of two concurrent halves is enqueued: each table is credited once)
+    double enter_level_alg_bytes(size_t n, unsigned l) const {
         double e = (double)((size_t)1 << (l - 1));
-        return sizeof(E) * (4.0 * (l - 1) * (double)n + 8.0 * (e - 1) + 3.0 * (double)n + 2.0 * e);
+        return sizeof(E) * (4.0 * (l - 1) * (double)n + 3.0 * (double)n + tblw_ * (8.0 * (e - 1) + 2.0 * e));
     }
-    static double exit_level_alg_bytes(size_t n, unsigned l) {
+    double exit_level_alg_bytes(size_t n, unsigned l) const {
         double e = (double)((size_t)1 << (l - 1));
-        return sizeof(E) * (8.0 * (l - 1) * (double)n + 32.0 * (e - 1) + 8.5 * (double)n + 8.5 * e);
+        return sizeof(E) * (8.0 * (l - 1) * (double)n + 8.5 * (double)n + tblw_ * (32.0 * (e - 1) + 8.5 * e));
     }
+#ifndef ECFFT_SPLIT_MIN_LOG
+#define ECFFT_SPLIT_MIN_LOG 16
+#endif
+    static constexpr unsigned kSplitMinLog = ECFFT_SPLIT_MIN_LOG;   // single transforms of at least 2^this run as two concurrent halves
     static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
     bool exit(const E* in, E* out, size_t n1, size_t count, hipStream_t s) {
-        const size_t n = n1 * count;      // all sizes below are totals over the batch; the level count comes from n1
+        const size_t n = n1 * count;
         if (n1 == 1) { if (in != out) (void)hipMemcpyAsync(out, in, n * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
         if (!ensure_scratch(n)) return false;
-        E* bufA = scratch_; E* bufB = scratch_ + n; E* G = scratch_ + 2 * n; E* H = scratch_ + 3 * n;
-        const E* cur = in;
         unsigned ln = ilog2(n1);
+        if (count == 1 && ln >= kSplitMinLog && side_) {
+            // top level on the whole array, then its two output blocks [u0 | v0] are independent EXITs of n/2: two streams
+            E* Y = scratch_; E* sA = scratch_ + n; E* sB = sA + 3 * (n / 2);
+            exit_levels(in, Y, n, 1, s, sA, ln, ln);
+            fork(s);
+            exit_levels(Y, out, n / 2, 1, s, sA, ln - 1, 1);
+            tblw_ = 0.0; exit_levels(Y + n / 2, out + n / 2, n / 2, 1, side_, sB, ln - 1, 1); tblw_ = 1.0;
+            join(s);
+        } else {
+            exit_levels(in, out, n1, count, s, scratch_, ln, 1);
+        }
+        return true;
+    }
+    // levels l_from down to l_to of EXIT on count arrays of n1 evaluations; base = 3*n1*count elements of scratch
+    void exit_levels(const E* in, E* out, size_t n1, size_t count, hipStream_t s, E* base, unsigned l_from, unsigned l_to) const {
+        const size_t n = n1 * count;      // all sizes below are totals over the batch; the level count comes from n1
+        E* bufA = base; E* bufB = base + n; E* G = base + 2 * n; E* H = G + n / 2;
+        const E* cur = in;
         size_t nh = n / 2;
-        unsigned l_stop = ln >= kLogLow ? kLogLow : 0;      // levels l_stop..1 run fused in k_exit_low
-        for (unsigned l = ln; l > l_stop; --l) {
+        unsigned l_stop = (l_to == 1 && l_from >= kLogLow) ? kLogLow : l_to - 1;      // levels l_stop..1 run fused in k_exit_low
+        for (unsigned l = l_from; l > l_stop; --l) {
             const Tree& T = trees_[l];
-            E* dst = (l == 1 && out != in) ? out : (cur == bufA ? bufB : bufA);
+            E* dst = (l == l_to && out != in) ? out : (cur == bufA ? bufB : bufA);
             // The reference's pointwise steps of this level (8.5 n + 8.5 e algorithmic element moves)
             // are all folded into the first load / last store of the four EXTEND cores:
             //   core 1  load  t0 = e0 * (xinv_even / W0)                    [t0 = e0/a0        : n + e   ]
@@ -358,7 +399,7 @@ public:
             //   core 3  load  t0' = h0~ * (c_even xinv_even)                 [h*c and t0'       : 3n + 3e ]
             //           store h1'~ = H * (c_odd zinv) - g1'~ * (x_odd zinv)  [h1'               : 1.5n + 2e]
             //   core 4  store u0 = W0 q0~ ; v0 = (e0 - u0) * xinv_even       [exit split        : 1.5n + 0.5e]
-            double se = sizeof(E), ee = (double)T.e;
+            double se = sizeof(E), ee = (double)T.e * tblw_;
             IoDesc<E> io1 = io_plain(cur, G);
             io1.src_stride = 2; io1.src_off = 0; io1.ld_mode = LD_SCALE; io1.ld_tbl = T.A1;
             io1.st_mode = ST_AXPBY; io1.st_a = T.NB2; io1.st_b = T.B1; io1.aux = cur; io1.aux_stride = 2; io1.aux_off = 1; io1.aux_out = H;
@@ -375,7 +416,7 @@ public:
             extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee), 0, nullptr, f3);
             cur = dst;
         }
-        if (l_stop) {
+        if (l_to == 1 && l_from >= kLogLow) {
             E* dst = out != in ? out : (cur == bufA ? bufB : bufA);
             double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += exit_level_alg_bytes(n, l);
             ECFFT_LAUNCH(KC_FUSED_EXIT, bytes, (k_exit_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
@@ -383,7 +424,6 @@ public:
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
-        return true;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -536,14 +576,19 @@ private:
         if (scratch_) (void)hipFree(scratch_);
         if (d_trees_) (void)hipFree(d_trees_);
         d_trees_ = nullptr;
+        if (side_) { (void)hipStreamDestroy(side_); side_ = nullptr; }
+        if (ev_fork_) { (void)hipEventDestroy(ev_fork_); ev_fork_ = nullptr; }
+        if (ev_join_) { (void)hipEventDestroy(ev_join_); ev_join_ = nullptr; }
         arena_ = nullptr; scratch_ = nullptr;
     }
 
+    void fork(hipStream_t s) const { (void)hipEventRecord(ev_fork_, s); (void)hipStreamWaitEvent(side_, ev_fork_, 0); }
+    void join(hipStream_t s) const { (void)hipEventRecord(ev_join_, side_); (void)hipStreamWaitEvent(s, ev_join_, 0); }
     bool ensure_scratch(size_t nt) {
-        if (scratch_cap_ >= 4 * nt) return true;
+        if (scratch_cap_ >= 5 * nt) return true;
         if (scratch_) { (void)hipDeviceSynchronize(); (void)hipFree(scratch_); scratch_ = nullptr; scratch_cap_ = 0; }
-        if (hipMalloc(&scratch_, 4 * nt * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: scratch allocation of %zu elements failed\n", 4 * nt); return false; }
-        scratch_cap_ = 4 * nt;
+        if (hipMalloc(&scratch_, 5 * nt * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: scratch allocation of %zu elements failed\n", 5 * nt); return false; }
+        scratch_cap_ = 5 * nt;
         return true;
     }
     bool finish_api(hipStream_t s) {
@@ -809,6 +854,8 @@ private:
     std::vector<void*> temps_;
     std::mutex mu_;
     mutable Profiler prof_;
+    hipStream_t side_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
 };
 
 }  // namespace ecfft
