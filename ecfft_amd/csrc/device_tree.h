@@ -119,8 +119,10 @@ public:
         ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
         // transform scratch: 5 N (grown on demand for batched calls); side stream for the two-halves schedule
         if (!ensure_scratch(N_)) return false;
-        if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess) { side_ = nullptr; }
+        for (nside_ = 0; nside_ < (1 << kSplitDepth) - 1 && nside_ < kMaxSides; ++nside_) {
+            if (hipStreamCreateWithFlags(&sides_[nside_], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_[nside_], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join_[nside_], hipEventDisableTiming) != hipSuccess) break;
+        }
         trees_.assign(L_ + 1, Tree{});
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
@@ -305,21 +307,30 @@ public:
         if (n == 1) { if (in != out) (void)hipMemcpyAsync(out, in, nt * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
         if (!ensure_scratch(nt)) return false;
         unsigned ln = ilog2(n);
-        if (count == 1 && ln >= kSplitMinLog && side_) {
-            // Two concurrent halves: levels 1..L-1 never mix the two half-blocks, so they run as two independent ENTERs of
-            // n/2 on two streams.  Their launches (each half as wide) interleave on the chip, so one half's load / store
-            // phases overlap the other's compute; only the top level runs on the whole array.
-            E* X = scratch_; E* sA = scratch_ + n; E* sB = sA + 3 * (n / 2);
-            fork(s);
-            enter_levels(in, X, n / 2, 1, s, sA, 1, ln - 1);
-            tblw_ = 0.0; enter_levels(in + n / 2, X + n / 2, n / 2, 1, side_, sB, 1, ln - 1); tblw_ = 1.0;
-            join(s);
-            enter_levels(X, out, n, 1, s, sA, ln, ln);
+        if (count == 1 && ln >= kSplitMinLog && nside_ > 0) {
+            int next_side = 0;
+            enter_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
         } else {
             enter_levels(in, out, n, count, s, scratch_, 1, ln);
         }
         return true;
     }
+    // Concurrent halves, recursively: levels 1..L-1 never mix the two half-blocks, so they run as two independent ENTERs
+    // of n/2 on two streams.  Their launches (each half as wide) interleave on the chip, so one half's load / store phases
+    // overlap the other's compute; only the top level runs on the whole array.  Scratch: f(n) = n + 2 f(n/2), f = 3n at a leaf.
+    void enter_rec(const E* in, E* out, size_t n, hipStream_t s, E* base, unsigned depth, int& next_side) {
+        unsigned ln = ilog2(n);
+        if (depth == 0 || ln < kSplitMinLog || next_side >= nside_) { enter_levels(in, out, n, 1, s, base, 1, ln); return; }
+        int me = next_side++;
+        hipStream_t s2 = sides_[me];
+        E* X = base; E* sA = base + n; E* sB = sA + scratch_need(n / 2, depth - 1);
+        (void)hipEventRecord(ev_fork_[me], s); (void)hipStreamWaitEvent(s2, ev_fork_[me], 0);
+        enter_rec(in, X, n / 2, s, sA, depth - 1, next_side);
+        double w = tblw_; tblw_ = 0.0; enter_rec(in + n / 2, X + n / 2, n / 2, s2, sB, depth - 1, next_side); tblw_ = w;
+        (void)hipEventRecord(ev_join_[me], s2); (void)hipStreamWaitEvent(s, ev_join_[me], 0);
+        enter_levels(X, out, n, 1, s, sA, ln, ln);
+    }
+    static size_t scratch_need(size_t n, unsigned depth) { return depth == 0 ? 3 * n : n + 2 * scratch_need(n / 2, depth - 1) > 4 * n ? n + 2 * scratch_need(n / 2, depth - 1) : 4 * n; }
     // levels l_begin..l_end of ENTER on count arrays of n elements; `in` = state before level l_begin; base = 3*n*count
     // elements of scratch (ping, pong, EXTEND work)
     void enter_levels(const E* in, E* out, size_t n, size_t count, hipStream_t s, E* base, unsigned l_begin, unsigned l_end) const {
@@ -359,7 +370,12 @@ public:
 #ifndef ECFFT_SPLIT_MIN_LOG
 #define ECFFT_SPLIT_MIN_LOG 16
 #endif
-    static constexpr unsigned kSplitMinLog = ECFFT_SPLIT_MIN_LOG;   // single transforms of at least 2^this run as two concurrent halves
+    static constexpr unsigned kSplitMinLog = ECFFT_SPLIT_MIN_LOG;   // single transforms of at least 2^this run as concurrent halves
+#ifndef ECFFT_SPLIT_DEPTH
+#define ECFFT_SPLIT_DEPTH 1
+#endif
+    static constexpr unsigned kSplitDepth = ECFFT_SPLIT_DEPTH;      // recursion depth of the halving (2^depth concurrent streams)
+    static constexpr int kMaxSides = 7;
     static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
@@ -368,18 +384,26 @@ public:
         if (n1 == 1) { if (in != out) (void)hipMemcpyAsync(out, in, n * sizeof(E), hipMemcpyDeviceToDevice, s); return true; }
         if (!ensure_scratch(n)) return false;
         unsigned ln = ilog2(n1);
-        if (count == 1 && ln >= kSplitMinLog && side_) {
-            // top level on the whole array, then its two output blocks [u0 | v0] are independent EXITs of n/2: two streams
-            E* Y = scratch_; E* sA = scratch_ + n; E* sB = sA + 3 * (n / 2);
-            exit_levels(in, Y, n, 1, s, sA, ln, ln);
-            fork(s);
-            exit_levels(Y, out, n / 2, 1, s, sA, ln - 1, 1);
-            tblw_ = 0.0; exit_levels(Y + n / 2, out + n / 2, n / 2, 1, side_, sB, ln - 1, 1); tblw_ = 1.0;
-            join(s);
+        if (count == 1 && ln >= kSplitMinLog && nside_ > 0) {
+            int next_side = 0;
+            exit_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
         } else {
             exit_levels(in, out, n1, count, s, scratch_, ln, 1);
         }
         return true;
+    }
+    // top level on the whole array, then its two output blocks [u0 | v0] are independent EXITs of n/2: two streams, recursively
+    void exit_rec(const E* in, E* out, size_t n, hipStream_t s, E* base, unsigned depth, int& next_side) {
+        unsigned ln = ilog2(n);
+        if (depth == 0 || ln < kSplitMinLog || next_side >= nside_) { exit_levels(in, out, n, 1, s, base, ln, 1); return; }
+        int me = next_side++;
+        hipStream_t s2 = sides_[me];
+        E* Y = base; E* sA = base + n; E* sB = sA + scratch_need(n / 2, depth - 1);
+        exit_levels(in, Y, n, 1, s, sA, ln, ln);
+        (void)hipEventRecord(ev_fork_[me], s); (void)hipStreamWaitEvent(s2, ev_fork_[me], 0);
+        exit_rec(Y, out, n / 2, s, sA, depth - 1, next_side);
+        double w = tblw_; tblw_ = 0.0; exit_rec(Y + n / 2, out + n / 2, n / 2, s2, sB, depth - 1, next_side); tblw_ = w;
+        (void)hipEventRecord(ev_join_[me], s2); (void)hipStreamWaitEvent(s, ev_join_[me], 0);
     }
     // levels l_from down to l_to of EXIT on count arrays of n1 evaluations; base = 3*n1*count elements of scratch
     void exit_levels(const E* in, E* out, size_t n1, size_t count, hipStream_t s, E* base, unsigned l_from, unsigned l_to) const {
@@ -576,19 +600,17 @@ private:
         if (scratch_) (void)hipFree(scratch_);
         if (d_trees_) (void)hipFree(d_trees_);
         d_trees_ = nullptr;
-        if (side_) { (void)hipStreamDestroy(side_); side_ = nullptr; }
-        if (ev_fork_) { (void)hipEventDestroy(ev_fork_); ev_fork_ = nullptr; }
-        if (ev_join_) { (void)hipEventDestroy(ev_join_); ev_join_ = nullptr; }
+        for (int i = 0; i < nside_; ++i) { (void)hipStreamDestroy(sides_[i]); (void)hipEventDestroy(ev_fork_[i]); (void)hipEventDestroy(ev_join_[i]); }
+        nside_ = 0;
         arena_ = nullptr; scratch_ = nullptr;
     }
 
-    void fork(hipStream_t s) const { (void)hipEventRecord(ev_fork_, s); (void)hipStreamWaitEvent(side_, ev_fork_, 0); }
-    void join(hipStream_t s) const { (void)hipEventRecord(ev_join_, side_); (void)hipStreamWaitEvent(s, ev_join_, 0); }
     bool ensure_scratch(size_t nt) {
-        if (scratch_cap_ >= 5 * nt) return true;
+        const size_t need = scratch_need(nt, kSplitDepth) > 5 * nt ? scratch_need(nt, kSplitDepth) : 5 * nt;
+        if (scratch_cap_ >= need) return true;
         if (scratch_) { (void)hipDeviceSynchronize(); (void)hipFree(scratch_); scratch_ = nullptr; scratch_cap_ = 0; }
-        if (hipMalloc(&scratch_, 5 * nt * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: scratch allocation of %zu elements failed\n", 5 * nt); return false; }
-        scratch_cap_ = 5 * nt;
+        if (hipMalloc(&scratch_, need * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: scratch allocation of %zu elements failed\n", need); return false; }
+        scratch_cap_ = need;
         return true;
     }
     bool finish_api(hipStream_t s) {
@@ -854,7 +876,7 @@ private:
     std::vector<void*> temps_;
     std::mutex mu_;
     mutable Profiler prof_;
-    hipStream_t side_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
 };
 
