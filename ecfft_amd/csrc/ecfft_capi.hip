@@ -120,8 +120,8 @@ int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap
         case ECFFT_TBL_Z1_S0: src = T.z1_s0; cnt = m / 2; break;
         case ECFFT_TBL_Z0_INV_S1: src = T.z0_inv_s1; cnt = m / 2; break;
         case ECFFT_TBL_Z1_INV_S0: src = T.z1_inv_s0; cnt = m / 2; break;
-        case ECFFT_TBL_Z0Z0_REM_XNN_S: src = T.z0z0; cnt = m; break;
-        case ECFFT_TBL_Z1Z1_REM_XNN_S: src = T.z1z1; cnt = m; break;
+        case ECFFT_TBL_Z0Z0_REM_XNN_S: src = T.z0z0; cnt = m < 2 ? 0 : m; break;   // empty for the 1-leaf tree (src/fftree.rs:459)
+        case ECFFT_TBL_Z1Z1_REM_XNN_S: src = T.z1z1; cnt = m < 2 ? 0 : m; break;
         case ECFFT_TBL_F: cnt = 2 * m; break;
         case ECFFT_TBL_RECOMBINE: case ECFFT_TBL_DECOMPOSE: cnt = 4 * m; break;
         default: return ECFFT_ERR_BAD_ARG;
@@ -483,6 +483,23 @@ int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t
     if (launches) *launches = p.launches(cls);
     if (ms_total) *ms_total = p.ms(cls);
     if (alg_bytes_total) *alg_bytes_total = p.bytes(cls);
+    return ECFFT_OK;
+}
+
+int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n) {
+    if (!in || !out) return ECFFT_ERR_BAD_ARG;
+    if (field == ECFFT_FIELD_M31) { if (in != out) memmove(out, in, n * 4); return ECFFT_OK; }
+    if (field != ECFFT_FIELD_SECP256K1) return ECFFT_ERR_BAD_ARG;
+    if (in != out) memmove(out, in, n * 32);
+    secp_from_mont_host((Fe256*)out, n);
+    return ECFFT_OK;
+}
+int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n) {
+    if (!in || !out) return ECFFT_ERR_BAD_ARG;
+    if (field == ECFFT_FIELD_M31) { if (in != out) memmove(out, in, n * 4); return ECFFT_OK; }
+    if (field != ECFFT_FIELD_SECP256K1) return ECFFT_ERR_BAD_ARG;
+    if (in != out) memmove(out, in, n * 32);
+    secp_to_mont_host((Fe256*)out, n);
     return ECFFT_OK;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -73,6 +73,8 @@ def lib():
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+        L.ecfft_elems_to_standard.restype, L.ecfft_elems_to_standard.argtypes = ci, [ci, vp, vp, sz]
+        L.ecfft_elems_from_standard.restype, L.ecfft_elems_from_standard.argtypes = ci, [ci, vp, vp, sz]
         L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
         L.ecfft_enter_many.restype, L.ecfft_enter_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
         L.ecfft_exit_many.restype, L.ecfft_exit_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
@@ -123,6 +125,17 @@ class Field:
         _check(rc)
         return FFTree(self, h, device)
 
+    def to_standard(self, a):
+        """in-memory elements -> standard-form little-endian integers (same array shape)"""
+        a = np.ascontiguousarray(a, self.dtype); out = np.empty_like(a)
+        _check(lib().ecfft_elems_to_standard(self.id, a.ctypes.data, out.ctypes.data, a.shape[0]))
+        return out
+
+    def from_standard(self, a):
+        a = np.ascontiguousarray(a, self.dtype); out = np.empty_like(a)
+        _check(lib().ecfft_elems_from_standard(self.id, a.ctypes.data, out.ctypes.data, a.shape[0]))
+        return out
+
     def build_points(self, n):
         """host-only: (f[2n], map_num[log n, 3], map_den[log n, 3]) — leaves are f[n:]."""
         ln = max(n.bit_length() - 1, 0)
@@ -142,7 +155,7 @@ class Field:
         n = leaves.shape[0]
         h = ctypes.c_void_p()
         _check(lib().ecfft_fftree_new(self.id, leaves.ctypes.data, n, map_num.ctypes.data, map_den.ctypes.data, device, ctypes.byref(h)))
-        return FFTree(self, h, device)
+        return FFTree(self, h, device, maps=(map_num, map_den))
 
 
 secp256k1 = Field("secp256k1", 0, np.uint64, 4)
@@ -157,9 +170,12 @@ def _is_torch(x):
 class FFTree:
     """Device-resident `FFTree<F>` (whole subtree chain).  `&self` methods, immutable after build."""
 
-    def __init__(self, field, handle, device):
+    def __init__(self, field, handle, device, maps=None):
         self.field, self._h, self.device = field, handle, device
         self.n = lib().ecfft_tree_size(handle)
+        self._from_build = maps is None          # build_fftree: the maps are those of build_points(n)
+        if maps is not None:
+            self._num, self._den = maps
 
     def __del__(self):
         try:
@@ -302,6 +318,14 @@ class FFTree:
     def leaves(self, m=None):
         m = self.n if m is None else m
         return self.table(TBL_F, m)[m:]
+
+    def rational_map(self, k):
+        """rational_maps[k] (src/fftree.rs:28) as (numerator[3], denominator[3]) coefficients, low -> high, zero padded"""
+        if not hasattr(self, "_maps"):
+            _, num, den = self.field.build_points(self.n) if self._from_build else (None, self._num, self._den)
+            self._maps = (num, den)
+        num, den = self._maps
+        return num[3 * k:3 * k + 3], den[3 * k:3 * k + 3]
 
     def subtree_with_size(self, n):
         """src/fftree.rs:489-496 — the chain lives in one context, so this is a size check + view."""

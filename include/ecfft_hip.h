@@ -140,6 +140,12 @@ int ecfft_profile_classes(void);
 int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t* launches, double* ms_total,
                        double* alg_bytes_total);
 
+/* Element representation converters (host buffers, no GPU needed): the crate's in-memory form <-> the STANDARD-form
+ * little-endian integer that ark-serialize writes (32 bytes for secp256k1, 4 for M31).  Used by the FFTree wire-format
+ * reader/writer (ecfft_amd/serialize.py, reference: src/fftree.rs:507-660). */
+int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n);
+int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
+
 /* library / device identification for logs: writes a NUL-terminated string */
 int ecfft_device_info(int device, char* buf, size_t cap);
 

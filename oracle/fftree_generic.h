@@ -522,8 +522,8 @@ const void* ORA(table)(const void* tv, size_t m, int which, size_t* count) {
         case ORA_T_Z1_S0: p = t->z1_s0; c = n / 2; break;
         case ORA_T_Z0_INV_S1: p = t->z0_inv_s1; c = n / 2; break;
         case ORA_T_Z1_INV_S0: p = t->z1_inv_s0; c = n / 2; break;
-        case ORA_T_Z0Z0: p = t->z0z0_rem_xnn_s; c = n; break;
-        case ORA_T_Z1Z1: p = t->z1z1_rem_xnn_s; c = n; break;
+        case ORA_T_Z0Z0: p = t->z0z0_rem_xnn_s; c = n < 2 ? 0 : n; break;   /* Ordering::Less => left empty (src/fftree.rs:459) */
+        case ORA_T_Z1Z1: p = t->z1z1_rem_xnn_s; c = n < 2 ? 0 : n; break;
         default: return NULL;
     }
     if (count) *count = c;
