@@ -20,10 +20,12 @@ struct M31 {
     __host__ __device__ static inline elem add(elem a, elem b) { uint32_t s = a + b; return s >= P ? s - P : s; }
     __host__ __device__ static inline elem sub(elem a, elem b) { return a >= b ? a - b : a + P - b; }
     __host__ __device__ static inline elem neg(elem a) { return a ? P - a : 0; }
-    __host__ __device__ static inline elem red64(uint64_t t) {  // t < 2^63
-        uint32_t r = (uint32_t)(t & P) + (uint32_t)((t >> 31) & P) + (uint32_t)(t >> 62);
-        r = (r & P) + (r >> 31);
-        return r >= P ? r - P : r;
+    __host__ __device__ static inline elem red64(uint64_t t) {  // t < 2^62 + 2^31 (a product of residues plus a residue)
+        uint32_t lo = (uint32_t)t & P, hi = (uint32_t)(t >> 31);     // hi <= 2^31, so lo + hi < 2^32
+        uint32_t r = lo + hi;
+        r = (r & P) + (r >> 31);                                     // <= 2^31
+        uint32_t d = r - P;                                          // wraps to a huge value when r < P
+        return d < r ? d : r;
     }
     __host__ __device__ static inline elem mul(elem t, elem x) { return red64((uint64_t)t * x); }
     __host__ __device__ static inline elem mul_add(elem t, elem x, elem c) { return red64((uint64_t)t * x + c); }
