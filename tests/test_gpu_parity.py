@@ -174,6 +174,26 @@ def test_config2_secp_2e16_bit_exact_vs_cpu(gpu, gpu_tree, oracle_mod):
     ev = ot.enter(c)
     assert np.array_equal(t.enter(c), ev)
     assert np.array_equal(t.exit(ev), c)
+    # EXIT of arbitrary evaluations and EXTEND of arbitrary vectors at this size (column passes, fused boundary passes and
+    # the two-halves schedule are all active from 2^16 up)
+    r = rand_elems(F, 1 << 16, 0x5EED0012)
+    assert np.array_equal(t.exit(r), ot.exit(r))
+    h = r[: 1 << 15]
+    assert np.array_equal(t.extend(h, gpu.Moiety.S1), ot.extend(h, oracle_mod.S1))
+    assert np.array_equal(t.extend(h, gpu.Moiety.S0), ot.extend(h, oracle_mod.S0))
+
+
+def test_m31_2e18_bit_exact_vs_cpu(gpu, gpu_tree, oracle_mod):
+    """M31 at a size where its column passes (tile 8192) and the two-halves schedule are active, against the CPU path"""
+    F = oracle_mod.field("m31")
+    ot = F.build_fftree(1 << 18)
+    t = gpu_tree("m31", 1 << 18)
+    c = rand_elems(F, 1 << 18, 77)
+    ev = ot.enter(c)
+    assert np.array_equal(t.enter(c), ev)
+    r = rand_elems(F, 1 << 18, 78)
+    assert np.array_equal(t.exit(r), ot.exit(r))
+    assert np.array_equal(t.extend(r[: 1 << 17], gpu.Moiety.S1), ot.extend(r[: 1 << 17], oracle_mod.S1))
 
 
 @pytest.mark.parametrize("field,log_n", [("secp256k1", 20), ("m31", 22)])
