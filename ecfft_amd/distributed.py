@@ -51,6 +51,17 @@ class HipOps:
         self.tree.extend_local_block(shard, e, moiety, log_p)
 
 
+def _a2a(recv, send, group=None, **kw):
+    """all_to_all_single; with the gloo backend (functional tests: several ranks sharing one GPU) device tensors are
+    staged through host memory, with nccl (= RCCL over xGMI) they go GPU to GPU."""
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), group=group, **kw)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, group=group, **kw)
+
+
 def _rows(t, n_elems):
     """view a shard as [n_elems, limbs] whatever the limb count"""
     return t.reshape(n_elems, -1)
@@ -61,7 +72,7 @@ def block_to_cyclic(x, world, group=None):
     c = x.shape[0]
     send = _rows(x, c).reshape(c // world, world, -1).transpose(0, 1).contiguous()   # [P, c/P, limbs]: row q = x[q::P]
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    _a2a(recv.view(-1), send.view(-1), group)
     return recv.reshape(c, -1)                                                       # source-rank major = ascending j'
 
 
@@ -70,7 +81,7 @@ def cyclic_to_block(y, world, group=None):
     c = y.shape[0]
     send = _rows(y, c).contiguous()                                                  # chunk r = y[r*c/P:(r+1)*c/P] -> rank r
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    _a2a(recv.view(-1), send.view(-1), group)
     return recv.reshape(world, c // world, -1).transpose(0, 1).contiguous().reshape(c, -1)
 
 
@@ -136,7 +147,7 @@ def _a2a_split(pieces, dests, srcs, piece_len, Q, like, group):
         out_split[s_] += piece_len
     send = torch.cat(pieces).contiguous()
     recv = torch.empty(piece_len * len(srcs), dtype=like.dtype, device=like.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    _a2a(recv, send, group, output_split_sizes=out_split, input_split_sizes=in_split)
     return [recv[k * piece_len:(k + 1) * piece_len] for k in range(len(srcs))]
 
 

@@ -27,6 +27,18 @@ def test_extend_sharded_gloo(world, oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_transforms_with_hip_ops(world):
+    """the whole multi-GPU path with the real HIP local ops: `world` ranks sharing cuda:0, gloo for the all-to-alls
+    (staged through host memory); results must equal the single-GPU transforms bit for bit"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("secp256k1", 1 << 8, 2)])
 def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
     """the HIP shard kernels (cyclic top stages with strided tables, block-local fused stages with
