@@ -88,8 +88,9 @@ def main():
     ap.add_argument("--field", default="secp256k1", choices=["secp256k1", "m31"])
     ap.add_argument("--cpu-log-n", type=int, default=15, help="size of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event pass")
-    ap.add_argument("--mode", default="enter-exit", choices=["enter-exit", "extend-split"],
-                    help="extend-split: BASELINE configs[3] — ONE EXTEND of 2^log-n evaluations split over the ranks with RCCL all-to-all")
+    ap.add_argument("--mode", default="enter-exit", choices=["enter-exit", "extend-split", "enter-exit-split"],
+                    help="extend-split: BASELINE configs[3] — ONE EXTEND of 2^log-n evaluations split over the ranks with RCCL all-to-all; "
+                         "enter-exit-split: ONE ENTER+EXIT of 2^log-n coefficients split over the ranks (strong scaling)")
     ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
     args = ap.parse_args()
 
@@ -119,6 +120,8 @@ def main():
 
     if args.mode == "extend-split":
         return extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev)
+    if args.mode == "enter-exit-split":
+        return enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev)
 
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
@@ -283,6 +286,58 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
                           "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
                           "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1} (BASELINE.json configs[3])", "e": e,
                                      "parallelism": f"evaluation domain block-split over {world} GPU(s), 4 all_to_all_single per EXTEND" if world > 1 else "single GPU"},
+                          "round_trip_ok": ok}))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda"):
+    """ONE ENTER followed by ONE EXIT of n = 2^log_n coefficients with the evaluation domain block-split over the ranks
+    (ecfft_amd/distributed.py: local low levels, split EXTENDs + table_fma + one all-to-all per top level).  Strong
+    scaling.  Checked by EXIT(ENTER(c)) == c on every rank."""
+    from ecfft_amd import distributed as D
+    n = 1 << args.log_n
+    F = ecfft_amd.FIELDS[args.field]
+    tree = F.build_fftree(n, device=local_rank)
+    c = n // world
+    host = synth(args.field, n, 0x5EED0005)[rank * c:(rank + 1) * c]
+    x = torch.from_numpy((host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).reshape(c, -1).copy()).cuda()
+    ops = D.HipOps(tree)
+    groups = D.make_groups() if world > 1 else {}
+
+    def step():
+        if world == 1:
+            ev = tree.enter(x)
+            return tree.exit(ev)
+        ev = D.enter_sharded(ops, x, n, groups)
+        return D.exit_sharded(ops, ev, n, groups)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        back = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        back = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ok = bool(torch.equal(back.reshape(x.shape), x))
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
+        fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
+    if rank == 0:
+        we, wx = w_mul(n)
+        print(json.dumps({"metric": f"{args.field} Fp field-mul/s, one ENTER+EXIT at n=2^{args.log_n} split over {world} GPU(s)",
+                          "value": (we + wx) * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+                          "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT, one transform", "n": n,
+                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s); levels above n/P use split EXTENDs and one all_to_all_single per level" if world > 1 else "single GPU"},
                           "round_trip_ok": ok}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
