@@ -225,6 +225,45 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
     for (uint32_t j = tid; j < T; j += kBlockLds) io_store<F>(io, base + j, log_e, tile[j]);
 }
 
+// column-tile variant of stage_sweep: pair (row r, column cc) with partner d rows below; table entry ((r mod d) << log_hs) + c0 + cc
+template <class F, bool DEC>
+__device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const typename F::elem* __restrict__ pa, const typename F::elem* __restrict__ pb,
+                                                uint32_t sft, uint32_t log_c, uint32_t log_hs, size_t c0, uint32_t npairs, uint32_t tid) {
+    using E = typename F::elem;
+    const uint32_t C = 1u << log_c, d = 1u << sft;
+    if constexpr (sizeof(E) == 4) {
+        if (log_c >= 2) {
+            for (uint32_t g4 = tid; g4 < (npairs >> 2); g4 += kBlockLds) {
+                const uint32_t g = g4 << 2, cc = g & (C - 1), pr = g >> log_c;
+                const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
+                const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
+                const uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+                uint4 va = *reinterpret_cast<const uint4*>(tile + lo), vb = *reinterpret_cast<const uint4*>(tile + hi);
+                const uint4 v0 = *reinterpret_cast<const uint4*>(pa + i), v1 = *reinterpret_cast<const uint4*>(pb + i);
+                uint32_t xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+                const uint32_t t0[4] = {v0.x, v0.y, v0.z, v0.w}, t1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (DEC) { E q1 = F::mul(t1[c], F::sub(xb[c], xa[c])); xa[c] = F::mul_add(t0[c], q1, xa[c]); xb[c] = q1; }
+                    else { E o0 = F::mul_add(t0[c], xb[c], xa[c]), o1 = F::mul_add(t1[c], xb[c], xa[c]); xa[c] = o0; xb[c] = o1; }
+                }
+                *reinterpret_cast<uint4*>(tile + lo) = make_uint4(xa[0], xa[1], xa[2], xa[3]);
+                *reinterpret_cast<uint4*>(tile + hi) = make_uint4(xb[0], xb[1], xb[2], xb[3]);
+            }
+            return;
+        }
+    }
+    for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+        const uint32_t cc = g & (C - 1), pr = g >> log_c;
+        const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
+        const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
+        const uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+        E a = tile[lo], b = tile[hi];
+        if (DEC) { E q1 = F::mul(pb[i], F::sub(b, a)); tile[lo] = F::mul_add(pa[i], q1, a); tile[hi] = q1; }
+        else { tile[lo] = F::mul_add(pa[i], b, a); tile[hi] = F::mul_add(pb[i], b, a); }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-fused butterfly stages, "column kernel": the R = kb-ka+1 consecutive stages ka..kb whose pair
 // distances (h_ka = hs*2^(R-1) ... h_kb = hs) are too large for a contiguous tile.  A workgroup
@@ -261,24 +300,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
         const uint32_t k = DECOMPOSE ? ka + st : kb - st;
         const uint32_t s = kb - k, d = 1u << s;                      // row distance of the pair
         const size_t h = hs << s;
-        const E* pa = ta + (e - 2 * h);
-        const E* pb = tb + (e - 2 * h);
-#pragma unroll
-        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
-            uint32_t cc = g & (C - 1), pr = g >> log_c;
-            uint32_t r = ((pr >> s) << (s + 1)) | (pr & (d - 1));
-            size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
-            uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
-            E a = tile[lo], b = tile[hi];
-            if (DECOMPOSE) {
-                E q1 = F::mul(pb[i], F::sub(b, a));
-                E q0 = F::mul_add(pa[i], q1, a);
-                tile[lo] = q0; tile[hi] = q1;
-            } else {
-                tile[lo] = F::mul_add(pa[i], b, a);
-                tile[hi] = F::mul_add(pb[i], b, a);
-            }
-        }
+        col_stage_sweep<F, DECOMPOSE>(tile, ta + (e - 2 * h), tb + (e - 2 * h), s, log_c, log_hs, c0, npairs, tid);
         __syncthreads();
     }
 #pragma unroll
@@ -324,23 +346,8 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col_mid(IoDesc<typename
             const uint32_t k = dec ? ka + st : kb - st;
             const uint32_t sft = kb - k, d = 1u << sft;
             const size_t h = hs << sft;
-            const E* pa = (dec ? np0 : p0) + (e - 2 * h);
-            const E* pb = (dec ? dinv : p1) + (e - 2 * h);
-            for (uint32_t g = tid; g < npairs; g += kBlockLds) {
-                uint32_t cc = g & (C - 1), pr = g >> log_c;
-                uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
-                size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
-                uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
-                E a = tile[lo], b = tile[hi];
-                if (dec) {
-                    E q1 = F::mul(pb[i], F::sub(b, a));
-                    E q0 = F::mul_add(pa[i], q1, a);
-                    tile[lo] = q0; tile[hi] = q1;
-                } else {
-                    tile[lo] = F::mul_add(pa[i], b, a);
-                    tile[hi] = F::mul_add(pb[i], b, a);
-                }
-            }
+            if (dec) col_stage_sweep<F, true>(tile, np0 + (e - 2 * h), dinv + (e - 2 * h), sft, log_c, log_hs, c0, npairs, tid);
+            else col_stage_sweep<F, false>(tile, p0 + (e - 2 * h), p1 + (e - 2 * h), sft, log_c, log_hs, c0, npairs, tid);
             __syncthreads();
         }
         if (!dec) {
