@@ -204,7 +204,7 @@ public:
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
-                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), ((size_t)sizeof(E)) << log_ct, s,
+                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R), s,
                              d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
                 return true;
             }
@@ -231,7 +231,7 @@ public:
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
                 const bool ct = (log_ct == kLogColTileMax && sizeof(E) == 4);
-                dim3 grid((unsigned)(total >> log_ct)); size_t lds = ((size_t)sizeof(E)) << log_ct;
+                dim3 grid((unsigned)(total >> log_ct)); size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R);
                 if (P.kind == 0) {
                     if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
                     else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);

@@ -225,6 +225,15 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::
     for (uint32_t j = tid; j < T; j += kBlockLds) io_store<F>(io, base + j, log_e, tile[j]);
 }
 
+#ifndef ECFFT_COL_PAD
+#define ECFFT_COL_PAD 0
+#endif
+// LDS row stride of a column tile: C elements + optional padding.  Unpadded, the small-distance stages make consecutive lane
+// groups hit the same half of the 256-byte bank row (rows are 128 B at C = 4), a 4-way conflict on ds_read_b128 — but an
+// A/B on MI355X (pad 0 / 1 / 2 rows) showed no difference: the kernel is bound by the modular multiply, not by LDS.
+template <class E>
+__host__ __device__ constexpr uint32_t col_row_stride(uint32_t C) { return C + (sizeof(E) == 4 ? 4u * ECFFT_COL_PAD : 1u * ECFFT_COL_PAD); }
+
 // column-tile variant of stage_sweep: pair (row r, column cc) with partner d rows below; table entry ((r mod d) << log_hs) + c0 + cc
 template <class F, bool DEC>
 __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const typename F::elem* __restrict__ pa, const typename F::elem* __restrict__ pb,
@@ -237,7 +246,7 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
                 const uint32_t g = g4 << 2, cc = g & (C - 1), pr = g >> log_c;
                 const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
                 const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
-                const uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+                const uint32_t RS = col_row_stride<E>(C), lo = r * RS + cc, hi = lo + d * RS;
                 uint4 va = *reinterpret_cast<const uint4*>(tile + lo), vb = *reinterpret_cast<const uint4*>(tile + hi);
                 const uint4 v0 = *reinterpret_cast<const uint4*>(pa + i), v1 = *reinterpret_cast<const uint4*>(pb + i);
                 uint32_t xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
@@ -257,7 +266,7 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
         const uint32_t cc = g & (C - 1), pr = g >> log_c;
         const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
         const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
-        const uint32_t lo = (r << log_c) + cc, hi = lo + (d << log_c);
+        const uint32_t RS = col_row_stride<E>(C), lo = r * RS + cc, hi = lo + d * RS;
         E a = tile[lo], b = tile[hi];
         if (DEC) { E q1 = F::mul(pb[i], F::sub(b, a)); tile[lo] = F::mul_add(pa[i], q1, a); tile[hi] = q1; }
         else { tile[lo] = F::mul_add(pa[i], b, a); tile[hi] = F::mul_add(pb[i], b, a); }
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        tile[j] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
+        tile[r * col_row_stride<E>(C) + cc] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
     }
     __syncthreads();
     const uint32_t npairs = T >> 1;
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[j]);
+        io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[r * col_row_stride<E>(C) + cc]);
     }
 }
 
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col_mid(IoDesc<typename
     const size_t c0 = (chunk << log_c);
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        tile[j] = io.src[B + ((size_t)r << log_hs) + cc];
+        tile[r * col_row_stride<E>(C) + cc] = io.src[B + ((size_t)r << log_hs) + cc];
     }
     __syncthreads();
     const uint32_t npairs = T >> 1;
@@ -353,14 +362,14 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col_mid(IoDesc<typename
         if (!dec) {
             for (uint32_t j = tid; j < T; j += kBlockLds) {
                 uint32_t r = j >> log_c, cc = j & (C - 1);
-                tile[j] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[j]);
+                { const uint32_t q = r * col_row_stride<E>(C) + cc; tile[q] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[q]); }
             }
             __syncthreads();
         }
     }
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        io.dst[B + ((size_t)r << log_hs) + cc] = tile[j];
+        io.dst[B + ((size_t)r << log_hs) + cc] = tile[r * col_row_stride<E>(C) + cc];
     }
 }
 
