@@ -137,6 +137,9 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<typename F::elem
 #define ECFFT_BLOCK_LDS 512
 #endif
 constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS-fused kernels
+#ifndef ECFFT_MIN_WAVES
+#define ECFFT_MIN_WAVES 4                    // waves per SIMD the register allocator must leave room for
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // One butterfly stage over an LDS-resident array: `npairs` pairs at distance h = 2^lh, table entry = pair index mod h.
@@ -179,7 +182,7 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
 
 
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
-__global__ __launch_bounds__(kBlockLds, 4) void k_stages_lds(IoDesc<typename F::elem> io,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ np0,
                                                            const typename F::elem* __restrict__ dinv,
                                                            const typename F::elem* __restrict__ p0,
@@ -282,7 +285,7 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
 // stage k: (r mod d)*hs + c_global with d = 2^(kb-k).
 // ---------------------------------------------------------------------------------------------
 template <class F, bool DECOMPOSE, int LOG_TILE_CT>     // LOG_TILE_CT > 0: log2(tile elements) known at compile time
-__global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::elem> io,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDesc<typename F::elem> io,
                                                            const typename F::elem* __restrict__ ta,   // np0 | p0
                                                            const typename F::elem* __restrict__ tb,   // dinv | p1
                                                            uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_stages_col(IoDesc<typename F::
 // one HBM round trip instead of two.
 // ---------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(kBlockLds, 4) void k_stages_col_mid(IoDesc<typename F::elem> io,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(IoDesc<typename F::elem> io,
                                                                const typename F::elem* __restrict__ p0, const typename F::elem* __restrict__ p1,
                                                                const typename F::elem* __restrict__ np0, const typename F::elem* __restrict__ dinv,
                                                                uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
@@ -423,7 +426,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
 
 // ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
 template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds, 4) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                           const LevelTables<typename F::elem>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(kBlockLds, 4) void k_enter_low(typename F::elem* __
 // EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
 // DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
 template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds, 4) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                          const LevelTables<typename F::elem>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
