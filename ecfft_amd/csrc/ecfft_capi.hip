@@ -277,6 +277,32 @@ int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, co
 }
 }  // namespace
 
+template <class F>
+int run_selftest(int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
+    using E = typename F::elem;
+    if (!a || !b || !out || (op == 0 && !c) || op < 0 || op > 3) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device) || hipSetDevice(device) != hipSuccess) return ECFFT_ERR_HIP;
+    E *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+    size_t bytes = n * sizeof(E);
+    bool ok = hipMalloc(&da, bytes) == hipSuccess && hipMalloc(&db, bytes) == hipSuccess && hipMalloc(&dc, bytes) == hipSuccess && hipMalloc(&dout, bytes) == hipSuccess;
+    ok = ok && hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && c) ok = hipMemcpy(dc, c, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        const E *pa = da, *pb = db, *pc = dc; E* po = dout;
+        foreach_n(nullptr, n, [=] __device__(size_t i) {
+            E r;
+            if (op == 0) r = F::mul_add(pa[i], pb[i], pc[i]);
+            else if (op == 1) r = F::mul(pa[i], pb[i]);
+            else if (op == 2) r = F::sub(pa[i], pb[i]);
+            else r = F::add(pa[i], pb[i]);
+            po[i] = r;
+        });
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
+    return ok ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+
 extern "C" {
 
 size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
@@ -501,6 +527,12 @@ int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n) {
     if (in != out) memmove(out, in, n * 32);
     secp_to_mont_host((Fe256*)out, n);
     return ECFFT_OK;
+}
+
+int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
+    if (field == ECFFT_FIELD_SECP256K1) return run_selftest<Secp256k1>(op, a, b, c, out, n, device);
+    if (field == ECFFT_FIELD_M31) return run_selftest<M31>(op, a, b, c, out, n, device);
+    return ECFFT_ERR_BAD_ARG;
 }
 
 int ecfft_device_info(int device, char* buf, size_t cap) {

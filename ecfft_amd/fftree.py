@@ -28,7 +28,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_selftest_field", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -73,6 +73,7 @@ def lib():
         L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+        L.ecfft_selftest_field.restype, L.ecfft_selftest_field.argtypes = ci, [ci, ci, vp, vp, vp, vp, sz, ci]
         L.ecfft_elems_to_standard.restype, L.ecfft_elems_to_standard.argtypes = ci, [ci, vp, vp, sz]
         L.ecfft_elems_from_standard.restype, L.ecfft_elems_from_standard.argtypes = ci, [ci, vp, vp, sz]
         L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
@@ -124,6 +125,14 @@ class Field:
             return None
         _check(rc)
         return FFTree(self, h, device)
+
+    def selftest(self, op, a, b, c=None, device=0):
+        """device field arithmetic on raw residues (test hook): op 0 a*b+c, 1 a*b, 2 a-b, 3 a+b"""
+        a = np.ascontiguousarray(a, self.dtype); b = np.ascontiguousarray(b, self.dtype)
+        cc = None if c is None else np.ascontiguousarray(c, self.dtype)
+        out = np.empty_like(a)
+        _check(lib().ecfft_selftest_field(self.id, op, a.ctypes.data, b.ctypes.data, None if cc is None else cc.ctypes.data, out.ctypes.data, a.shape[0], device))
+        return out
 
     def to_standard(self, a):
         """in-memory elements -> standard-form little-endian integers (same array shape)"""

@@ -146,6 +146,11 @@ int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t
 int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n);
 int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
 
+/* Test hook: the DEVICE field arithmetic on raw residues (plain integers < p, no Montgomery interpretation), host buffers.
+ * op 0: out = a*b + c mod p   1: a*b   2: a - b   3: a + b.  Lets the tests drive the hand-written gfx950 multiply with
+ * directed operands (results next to p and 2^256, carry-out of the second fold) that random data never reaches. */
+int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device);
+
 /* library / device identification for logs: writes a NUL-terminated string */
 int ecfft_device_info(int device, char* buf, size_t cap);
 

@@ -1,0 +1,91 @@
+"""Directed tests of the DEVICE field arithmetic (hand-written gfx950 multiply, asm subtraction, M31 reduction) through
+ecfft_selftest_field: operands chosen so that results land next to p and 2^256, the second fold carries out, and the
+canonicalisation branch is taken — cases that uniformly random data reaches with probability < 2^-32 per lane."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P256 = 2**256 - 2**32 - 977
+C = 2**32 + 977
+P31 = 2**31 - 1
+
+
+def pack256(vals):
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for l in range(4):
+            out[i, l] = (v >> (64 * l)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def unpack256(a):
+    return [sum(int(a[i, l]) << (64 * l) for l in range(4)) for i in range(a.shape[0])]
+
+
+def directed_triples():
+    rnd = random.Random(7)
+    T = []
+    edge = [0, 1, 2, C, C - 1, C + 1, P256 - 1, P256 - 2, P256 - C, 2**255, 2**255 - 1, 2**128, 2**128 - 1, 2**224, (1 << 256) - C - 1 - 977,
+            0xFFFFFFFF, 0xFFFFFFFF00000000, (2**256 - 1) // 3, P256 // 2, P256 // 2 + 1]
+    for a in edge:
+        for b in edge:
+            T.append((a, b, rnd.choice(edge)))
+    # results that are exactly p-1, 0, 1 (value before canonicalisation in [p, 2^256) or just below p)
+    for _ in range(200):
+        t = rnd.randrange(1, P256)
+        for target in (P256 - 1, 0, 1, P256 - rnd.randrange(1, 2**40), rnd.randrange(0, 2**40)):
+            x = target * pow(t, -1, P256) % P256
+            T.append((t, x, 0))
+            c = rnd.randrange(P256)
+            x2 = (target - c) * pow(t, -1, P256) % P256
+            T.append((t, x2, c))
+    # carry-out of the second fold: t = 2^255, x even -> V = (x/2)*C just below a multiple of 2^256
+    for j in range(2, 400, 7):
+        half = (j * 2**256 - 1) // C
+        x = 2 * half
+        if x < P256:
+            T.append((2**255, x, 0))
+            T.append((2**255, x, P256 - 1))
+    # high words all ones before the fold
+    for _ in range(200):
+        T.append((P256 - rnd.randrange(1, 2**33), P256 - rnd.randrange(1, 2**33), P256 - rnd.randrange(1, 2**33)))
+    for _ in range(3000):
+        T.append((rnd.randrange(P256), rnd.randrange(P256), rnd.randrange(P256)))
+    return T
+
+
+def test_secp_mul_add_directed():
+    import ecfft_amd
+    F = ecfft_amd.secp256k1
+    T = directed_triples()
+    a, b, c = pack256([t[0] for t in T]), pack256([t[1] for t in T]), pack256([t[2] for t in T])
+    got = unpack256(F.selftest(0, a, b, c))
+    assert got == [(x * y + z) % P256 for x, y, z in T]
+    got = unpack256(F.selftest(1, a, b))
+    assert got == [(x * y) % P256 for x, y, z in T]
+
+
+def test_secp_add_sub_directed():
+    import ecfft_amd
+    F = ecfft_amd.secp256k1
+    T = directed_triples()
+    a, b = pack256([t[0] for t in T]), pack256([t[1] for t in T])
+    assert unpack256(F.selftest(2, a, b)) == [(x - y) % P256 for x, y, z in T]
+    assert unpack256(F.selftest(3, a, b)) == [(x + y) % P256 for x, y, z in T]
+
+
+def test_m31_directed():
+    import ecfft_amd
+    F = ecfft_amd.m31
+    rnd = random.Random(3)
+    edge = [0, 1, 2, P31 - 1, P31 - 2, 2**30, 2**30 - 1, 2**16, 46341, 46340, 65535, 65536]
+    T = [(a, b, c) for a in edge for b in edge for c in (0, 1, P31 - 1)]
+    T += [(rnd.randrange(P31), rnd.randrange(P31), rnd.randrange(P31)) for _ in range(20000)]
+    a = np.array([t[0] for t in T], dtype=np.uint32); b = np.array([t[1] for t in T], dtype=np.uint32); c = np.array([t[2] for t in T], dtype=np.uint32)
+    assert [int(v) for v in F.selftest(0, a, b, c)] == [(x * y + z) % P31 for x, y, z in T]
+    assert [int(v) for v in F.selftest(1, a, b)] == [(x * y) % P31 for x, y, z in T]
+    assert [int(v) for v in F.selftest(2, a, b)] == [(x - y) % P31 for x, y, z in T]
+    assert [int(v) for v in F.selftest(3, a, b)] == [(x + y) % P31 for x, y, z in T]

@@ -197,7 +197,12 @@ def gen_reduce():
     for k in range(3, 8):
         body.append(f"v_addc_co_u32_e32 %{Rr[k]}, vcc, 0, %{Rr[k]}, vcc")
     body.append(f"s_or_b64 %{OVF}, %{OVF}, vcc")
-    # q = r + (2^32 + 977); take q if the value overflowed 2^256 before or r >= p
+    # canonicalise: q = r + (2^32 + 977); take q if the value overflowed 2^256 before or r >= p.  r >= p needs r7 = 0xFFFFFFFF
+    # (probability 2^-32 per lane) and an overflow is rarer still, so the 17-instruction select sits behind a wave-uniform
+    # branch: 4 instructions on the fast path, identical results.
+    body.append(f"v_cmp_eq_u32_e32 vcc, -1, %{Rr[7]}")
+    body.append(f"s_or_b64 %{OVF2}, %{OVF}, vcc")
+    body.append("s_cbranch_scc0 .Lecfft_canon_done_%=")
     body.append(f"v_add_co_u32_e32 %{Q[0]}, vcc, 0x3d1, %{Rr[0]}")
     body.append(f"v_addc_co_u32_e32 %{Q[1]}, vcc, 1, %{Rr[1]}, vcc")
     for k in range(2, 8):
@@ -205,6 +210,7 @@ def gen_reduce():
     body.append(f"s_or_b64 %{OVF2}, %{OVF}, vcc")
     for k in range(8):
         body.append(f"v_cndmask_b32_e64 %{Rr[k]}, %{Rr[k]}, %{Q[k]}, %{OVF2}")
+    body.append(".Lecfft_canon_done_%=:")
     # s_or_b64 writes SCC: it must be declared, hipcc keeps loop compares live across asm statements
     L.append('        asm("' + "\\n\\t".join(body) + '"\n            : ' + ", ".join(outs) + "\n            : " + ", ".join(ins) + '\n            : "vcc", "scc");')
     L.append("        elem r; r.l[0] = r0; r.l[1] = r1; r.l[2] = r2; r.l[3] = r3; r.l[4] = r4; r.l[5] = r5; r.l[6] = r6; r.l[7] = r7;")
