@@ -85,7 +85,8 @@ template <class F>
 class DeviceChain {
 public:
     using E = typename F::elem;
-    using Tree = LevelTables<E>;   // per-tree table set (kernels.h); an array of them is mirrored on the device
+    using TE = typename F::telem;  // table constant in the form the kernels multiply by (secp256k1: the pair (t, t*2^128))
+    using Tree = LevelTables<F>;   // per-tree table set (kernels.h); an array of them is mirrored on the device
 
     ~DeviceChain() { release(); }
 
@@ -105,9 +106,10 @@ public:
         N_ = host_.n; L_ = ilog2(N_); device_ = device;
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
-        // arena: 16 elements per leaf per tree, chain sums to < 32 N; + f (2N) + den coefficients
+        // arena per tree of m leaves: 6m elements of reference tables (xnn, z*) + 10m table constants of the hot path
+        // (F::telem each); + f (2N) + den coefficients
         size_t total = 2 * N_ + 64;
-        for (unsigned l = 0; l <= L_; ++l) total += 16 * ((size_t)1 << l) + 512;
+        for (unsigned l = 0; l <= L_; ++l) total += (6 + 10 * kTeElems) * ((size_t)1 << l) + 1024;
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         f_ = take(2 * N_);
@@ -164,8 +166,8 @@ public:
     // direction, follows on `buf` with that load operator; if this core ends in a column pass, that pass and the next
     // core's first column pass run as ONE launch (k_stages_col_mid) and the function returns true; the next core is then
     // called with skip_first_col = true.
-    struct NextLoad { int ld_mode; const E* ld_tbl; double extra_first; };
-    bool extend_core(unsigned log_m, IoDesc<E> io, E* buf, size_t total, int srcpar, hipStream_t s,
+    struct NextLoad { int ld_mode; const TE* ld_tbl; double extra_first; };
+    bool extend_core(unsigned log_m, IoDesc<F> io, E* buf, size_t total, int srcpar, hipStream_t s,
                      double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0,
                      const NextLoad* next_ld = nullptr, bool skip_first_col = false) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
@@ -194,7 +196,7 @@ public:
         const bool fuse_tail = next_ld && nd >= 1 && (io.st_mode == ST_PLAIN || io.st_mode == ST_SCALE || io.st_mode == ST_AXPBY) && io.dst == buf;
         const int pi0 = (skip_first_col && nd >= 1) ? 1 : 0;
         for (int pi = pi0; pi < np; ++pi) {
-            IoDesc<E> d;
+            IoDesc<F> d;
             bool first = pi == 0, last = pi == np - 1;
             if (last && fuse_tail) {
                 // this core's last recombine group + the next core's first decompose group (same stages, same tiles)
@@ -209,10 +211,10 @@ public:
                 return true;
             }
             // load side
-            if (first) { d = io; } else { d = IoDesc<E>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
+            if (first) { d = io; } else { d = IoDesc<F>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
             // store side
             if (last) { d.dst = io.dst; d.st_mode = io.st_mode; d.st_a = io.st_a; d.st_b = io.st_b; d.aux = io.aux; d.aux_stride = io.aux_stride; d.aux_off = io.aux_off; d.aux_out = io.aux_out; }
-            else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
+            else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
             double extra = (first ? extra_first : 0.0) + (last ? extra_last : 0.0);
             const Pass& P = passes[pi];
             if (P.kind == 1) {
@@ -243,9 +245,9 @@ public:
         }
         return false;
     }
-    static IoDesc<E> io_plain(const E* src, E* dst) {
-        IoDesc<E> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;
-        d.dst = dst; d.st_mode = ST_PLAIN; d.st_a = d.st_b = d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr;
+    static IoDesc<F> io_plain(const E* src, E* dst) {
+        IoDesc<F> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;
+        d.dst = dst; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr;
         return d;
     }
 
@@ -255,7 +257,7 @@ public:
         unsigned log_m = ilog2(e) + 1;
         const Tree& T = trees_[log_m];
         size_t total = e * count; int src = 1 - target;
-        IoDesc<E> io = io_plain(in, out);
+        IoDesc<F> io = io_plain(in, out);
         io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[src];
         io.st_mode = ST_SCALE; io.st_a = T.w[target];
         extend_core(log_m, io, out, total, src, s);
@@ -350,7 +352,7 @@ public:
             const Tree& T = trees_[l];
             size_t e = T.e;
             E* dst = (l == l_end && out != in) ? out : (src == bufA ? bufB : bufA);
-            { IoDesc<E> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, nt, 0, s); }
+            { IoDesc<F> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, nt, 0, s); }
             ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * nt + 2.0 * e * tblw_), k_enter_combine<F>, dim3(nblocks(nt / 2)), dim3(kBlock), 0, s,
                          dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), nt / 2);
             src = dst;
@@ -424,18 +426,18 @@ public:
             //           store h1'~ = H * (c_odd zinv) - g1'~ * (x_odd zinv)  [h1'               : 1.5n + 2e]
             //   core 4  store u0 = W0 q0~ ; v0 = (e0 - u0) * xinv_even       [exit split        : 1.5n + 0.5e]
             double se = sizeof(E), ee = (double)T.e * tblw_;
-            IoDesc<E> io1 = io_plain(cur, G);
+            IoDesc<F> io1 = io_plain(cur, G);
             io1.src_stride = 2; io1.src_off = 0; io1.ld_mode = LD_SCALE; io1.ld_tbl = T.A1;
             io1.st_mode = ST_AXPBY; io1.st_a = T.NB2; io1.st_b = T.B1; io1.aux = cur; io1.aux_stride = 2; io1.aux_off = 1; io1.aux_out = H;
             // consecutive cores meet at a column pass on the same tiles: run those two passes as one launch (k_stages_col_mid)
             NextLoad nl2{LD_PLAIN, nullptr, 0.0}, nl3{LD_SCALE, T.C1, se * (3.0 * n + 3.0 * ee)}, nl4{LD_PLAIN, nullptr, 0.0};
             bool f1 = extend_core(l, io1, G, nh, 0, s, se * (1.0 * n + ee), se * (1.5 * n + 2.0 * ee), 0, &nl2, false);
             bool f2 = extend_core(l, io_plain(G, G), G, nh, 1, s, 0.0, 0.0, 0, &nl3, f1);
-            IoDesc<E> io3 = io_plain(G, G);
+            IoDesc<F> io3 = io_plain(G, G);
             io3.ld_mode = LD_SCALE; io3.ld_tbl = T.C1;
             io3.st_mode = ST_AXPBY; io3.st_a = T.NB2; io3.st_b = T.D1; io3.aux = H; io3.aux_stride = 1; io3.aux_off = 0; io3.aux_out = nullptr;
             bool f3 = extend_core(l, io3, G, nh, 0, s, f2 ? 0.0 : se * (3.0 * n + 3.0 * ee), se * (1.5 * n + 2.0 * ee), 0, &nl4, f2);
-            IoDesc<E> io4 = io_plain(G, dst);
+            IoDesc<F> io4 = io_plain(G, dst);
             io4.st_mode = ST_EXIT_SPLIT; io4.st_a = T.w[0]; io4.st_b = T.xie; io4.aux = cur; io4.aux_stride = 2; io4.aux_off = 0;
             extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee), 0, nullptr, f3);
             cur = dst;
@@ -588,6 +590,14 @@ private:
         if (arena_used_ + a > arena_cap_) { fprintf(stderr, "ecfft: internal error: table arena overflow\n"); abort(); }   // sized exactly in build(); unreachable
         E* p = arena_ + arena_used_; arena_used_ += a; return p;
     }
+    static constexpr size_t kTeElems = sizeof(TE) / sizeof(E);
+    static_assert(sizeof(TE) % sizeof(E) == 0, "table element must be a whole number of field elements");
+    // n table constants in the arena, filled from the plain values src[0..n)
+    TE* to_tables(const E* src, size_t n, hipStream_t s) {
+        TE* d = reinterpret_cast<TE*>(take(n * kTeElems));
+        foreach_n(s, n, [=] __device__(size_t i) { d[i] = F::to_table(src[i]); });
+        return d;
+    }
     E* temp(size_t n) {
         void* p = nullptr;
         if (hipMalloc(&p, (n ? n : 1) * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: temp alloc failed\n"); abort(); }
@@ -721,10 +731,12 @@ private:
         if (l == 0) return true;
         unsigned le = ilog2(e);
         size_t es = e > 1 ? e : 1;
+        // plain values first (temporaries), then the kernels' table form in the arena
+        E *hp0[2], *hp1[2], *hnp0[2], *hdinv[2], *hw[2], *hwinv[2];
         for (int sg = 0; sg < 2; ++sg) {
-            T.p0[sg] = take(es); T.p1[sg] = take(es); T.np0[sg] = take(es); T.dinv[sg] = take(es);
-            T.w[sg] = take(es); T.winv[sg] = take(es);
-            E *p0 = T.p0[sg], *p1 = T.p1[sg], *np0 = T.np0[sg], *dinv = T.dinv[sg];
+            hp0[sg] = temp(es); hp1[sg] = temp(es); hnp0[sg] = temp(es); hdinv[sg] = temp(es);
+            hw[sg] = temp(es); hwinv[sg] = temp(es);
+            E *p0 = hp0[sg], *p1 = hp1[sg], *np0 = hnp0[sg], *dinv = hdinv[sg];
             if (e > 1) {
                 // entry g of the concatenated stage tables: stage k = number of leading ones ... computed by scan
                 foreach_n(s, e - 1, [=] __device__(size_t g) {
@@ -741,7 +753,7 @@ private:
                 batch_inv(dinv, dinv, e - 1, s);
             }
             // normalisation weights W(s) of the leaves of parity sg (DESIGN.md "Normalised butterflies")
-            E* w = T.w[sg]; const E* den = den_;
+            E* w = hw[sg]; const E* den = den_;
             foreach_n(s, e, [=] __device__(size_t i) {
                 size_t j = 2 * i + sg;
                 E U = F::one(), C = F::one();
@@ -754,20 +766,31 @@ private:
                 }
                 w[i] = U;
             });
-            batch_inv(T.w[sg], T.winv[sg], e, s);
+            batch_inv(hw[sg], hwinv[sg], e, s);
         }
         // merged innermost stage pair (h = 1, stage k = le-1): out_j = a + c_j*(b - a) with
         // c_j = (p_j^target - p_0^source) / (p_1^source - p_0^source), table offset e-2 (kernels.h)
         for (int sg = 0; sg < 2; ++sg) {
-            T.inner[sg] = take(2);
+            E* in = temp(2);
             if (e > 1) {
-                E* in = T.inner[sg];
-                const E *sp0 = T.p0[sg] + (e - 2), *sdi = T.dinv[sg] + (e - 2), *tp0 = T.p0[1 - sg] + (e - 2), *tp1 = T.p1[1 - sg] + (e - 2);
+                const E *sp0 = hp0[sg] + (e - 2), *sdi = hdinv[sg] + (e - 2), *tp0 = hp0[1 - sg] + (e - 2), *tp1 = hp1[1 - sg] + (e - 2);
                 foreach_n(s, 1, [=] __device__(size_t) {
                     in[0] = F::mul(F::sub(tp0[0], sp0[0]), sdi[0]);
                     in[1] = F::mul(F::sub(tp1[0], sp0[0]), sdi[0]);
                 });
+            } else {
+                (void)hipMemsetAsync(in, 0, 2 * sizeof(E), s);
             }
+            T.inner[sg] = to_tables(in, 2, s);
+        }
+        for (int sg = 0; sg < 2; ++sg) {
+            if (e == 1) {   // no butterfly stage: the (never read) stage tables still get defined contents
+                (void)hipMemsetAsync(hp0[sg], 0, sizeof(E), s); (void)hipMemsetAsync(hp1[sg], 0, sizeof(E), s);
+                (void)hipMemsetAsync(hnp0[sg], 0, sizeof(E), s); (void)hipMemsetAsync(hdinv[sg], 0, sizeof(E), s);
+            }
+            T.p0[sg] = to_tables(hp0[sg], es, s); T.p1[sg] = to_tables(hp1[sg], es, s);
+            T.np0[sg] = to_tables(hnp0[sg], es, s); T.dinv[sg] = to_tables(hdinv[sg], es, s);
+            T.w[sg] = to_tables(hw[sg], es, s); T.winv[sg] = to_tables(hwinv[sg], es, s);
         }
         T.z0_s1 = take(es); T.z1_s0 = take(es); T.z0_inv_s1 = take(es); T.z1_inv_s0 = take(es);
         T.z0z0 = take(m); T.z1z1 = take(m);
@@ -840,11 +863,9 @@ private:
             b_modular_reduce(l, tmp, xa0i, xa1, T.z0z0, T.z1z1, s);
         }
         // fused pointwise tables of the hot path
-        T.xe = take(es); T.w1x = take(es); T.A1 = take(es); T.B1 = take(es); T.NB2 = take(es);
-        T.C1 = take(es); T.D1 = take(es); T.xie = take(es);
         {
-            E *xe = T.xe, *w1x = T.w1x, *A1 = T.A1, *B1 = T.B1, *NB2 = T.NB2, *C1 = T.C1, *D1 = T.D1, *xie = T.xie;
-            const E *xnn = T.xnn, *xi = T.xnn_inv, *w1 = T.w[1], *wi0 = T.winv[0], *wi1 = T.winv[1], *zi = T.z0_inv_s1, *c = T.z0z0;
+            E *xe = temp(es), *w1x = temp(es), *A1 = temp(es), *B1 = temp(es), *NB2 = temp(es), *C1 = temp(es), *D1 = temp(es), *xie = temp(es);
+            const E *xnn = T.xnn, *xi = T.xnn_inv, *w1 = hw[1], *wi0 = hwinv[0], *wi1 = hwinv[1], *zi = T.z0_inv_s1, *c = T.z0z0;
             foreach_n(s, e, [=] __device__(size_t i) {
                 E xo = xnn[2 * i + 1], xiev = xi[2 * i], z = zi[i];
                 xe[i] = xnn[2 * i];
@@ -856,6 +877,8 @@ private:
                 C1[i] = F::mul(c[2 * i], xiev);
                 D1[i] = F::mul(c[2 * i + 1], z);
             });
+            T.xe = to_tables(xe, es, s); T.w1x = to_tables(w1x, es, s); T.A1 = to_tables(A1, es, s); T.B1 = to_tables(B1, es, s);
+            T.NB2 = to_tables(NB2, es, s); T.C1 = to_tables(C1, es, s); T.D1 = to_tables(D1, es, s); T.xie = to_tables(xie, es, s);
         }
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) { fprintf(stderr, "ecfft: kernel launch failed: %s\n", hipGetErrorString(err)); return false; }

@@ -8,6 +8,7 @@ namespace ecfft {
 
 struct M31 {
     using elem = uint32_t;
+    using telem = uint32_t;    // table constant as the butterflies read it (secp256k1 stores a pair, see field_secp256k1.h)
     static constexpr int kBytes = 4;
     static constexpr int kFieldId = 1;
     static constexpr uint32_t P = 0x7FFFFFFFu;
@@ -29,6 +30,9 @@ struct M31 {
     }
     __host__ __device__ static inline elem mul(elem t, elem x) { return red64((uint64_t)t * x); }
     __host__ __device__ static inline elem mul_add(elem t, elem x, elem c) { return red64((uint64_t)t * x + c); }
+    __host__ __device__ static inline telem to_table(elem t) { return t; }
+    __host__ __device__ static inline elem tmul(telem t, elem x) { return mul(t, x); }
+    __host__ __device__ static inline elem tmul_add(telem t, elem x, elem c) { return mul_add(t, x, c); }
     __host__ __device__ static inline elem sqr(elem a) { return mul(a, a); }
     __host__ __device__ static inline elem pow_u64(elem a, uint64_t e) {
         elem r = 1;

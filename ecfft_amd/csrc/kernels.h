@@ -26,8 +26,8 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------------
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_decompose_stage(typename F::elem* __restrict__ buf,
-                                                             const typename F::elem* __restrict__ np0,
-                                                             const typename F::elem* __restrict__ dinv,
+                                                             const typename F::telem* __restrict__ np0,
+                                                             const typename F::telem* __restrict__ dinv,
                                                              uint32_t log_h, size_t npairs, uint32_t tstride, uint32_t toff) {
     // tstride/toff: table entry of local pair index i is i*tstride + toff (cyclic shards of a split EXTEND; 1/0 otherwise)
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -37,16 +37,16 @@ __global__ __launch_bounds__(kBlock) void k_decompose_stage(typename F::elem* __
     size_t idx = ((g >> log_h) << (log_h + 1)) + i;
     i = i * tstride + toff;
     typename F::elem a = buf[idx], b = buf[idx + h];
-    typename F::elem q1 = F::mul(dinv[i], F::sub(b, a));
-    typename F::elem q0 = F::mul_add(np0[i], q1, a);
+    typename F::elem q1 = F::tmul(dinv[i], F::sub(b, a));
+    typename F::elem q0 = F::tmul_add(np0[i], q1, a);
     buf[idx] = q0;
     buf[idx + h] = q1;
 }
 
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __restrict__ buf,
-                                                             const typename F::elem* __restrict__ p0,
-                                                             const typename F::elem* __restrict__ p1,
+                                                             const typename F::telem* __restrict__ p0,
+                                                             const typename F::telem* __restrict__ p1,
                                                              uint32_t log_h, size_t npairs, uint32_t tstride, uint32_t toff) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= npairs) return;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
     size_t idx = ((g >> log_h) << (log_h + 1)) + i;
     i = i * tstride + toff;
     typename F::elem a = buf[idx], b = buf[idx + h];
-    buf[idx] = F::mul_add(p0[i], b, a);
-    buf[idx + h] = F::mul_add(p1[i], b, a);
+    buf[idx] = F::tmul_add(p0[i], b, a);
+    buf[idx + h] = F::tmul_add(p1[i], b, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -68,39 +68,41 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
 enum { LD_PLAIN = 0, LD_SCALE = 1 };
 enum { ST_PLAIN = 0, ST_SCALE = 1, ST_AXPBY = 2, ST_EXIT_SPLIT = 3 };
 
-template <class E>
+template <class F>
 struct IoDesc {
+    using E = typename F::elem;
+    using TE = typename F::telem;
     // load:  x = [ld_tbl[i] *] src[src_stride*pos + src_off]
-    const E* src; uint32_t src_stride, src_off; int ld_mode; const E* ld_tbl;
+    const E* src; uint32_t src_stride, src_off; int ld_mode; const TE* ld_tbl;
     // store: ST_PLAIN  dst[pos] = x
     //        ST_SCALE  dst[pos] = st_a[i]*x
     //        ST_AXPBY  r = st_a[i]*x + st_b[i]*aux[aux_stride*pos + aux_off]; dst[pos] = r; aux_out[pos] = r (if set)
     //        ST_EXIT_SPLIT  u0 = st_a[i]*x; v0 = st_b[i]*(aux[2*pos] - u0); dst[b*2e + i] = u0; dst[b*2e + e + i] = v0  (b = pos / e)
-    E* dst; int st_mode; const E* st_a; const E* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out;
+    E* dst; int st_mode; const TE* st_a; const TE* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out;
 };
 
 template <class F>
-__device__ __forceinline__ typename F::elem io_load(const IoDesc<typename F::elem>& io, size_t pos, size_t emask) {
+__device__ __forceinline__ typename F::elem io_load(const IoDesc<F>& io, size_t pos, size_t emask) {
     typename F::elem v = io.src[(size_t)io.src_stride * pos + io.src_off];
-    if (io.ld_mode == LD_SCALE) v = F::mul(io.ld_tbl[pos & emask], v);
+    if (io.ld_mode == LD_SCALE) v = F::tmul(io.ld_tbl[pos & emask], v);
     return v;
 }
 template <class F>
-__device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, size_t pos, uint32_t log_e, const typename F::elem& x) {
+__device__ __forceinline__ void io_store(const IoDesc<F>& io, size_t pos, uint32_t log_e, const typename F::elem& x) {
     using E = typename F::elem;
     const size_t emask = ((size_t)1 << log_e) - 1, i = pos & emask;
     switch (io.st_mode) {
         case ST_PLAIN: io.dst[pos] = x; break;
-        case ST_SCALE: io.dst[pos] = F::mul(io.st_a[i], x); break;
+        case ST_SCALE: io.dst[pos] = F::tmul(io.st_a[i], x); break;
         case ST_AXPBY: {
-            E r = F::mul_add(io.st_a[i], x, F::mul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+            E r = F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
             io.dst[pos] = r;
             if (io.aux_out) io.aux_out[pos] = r;
             break;
         }
         default: {  // ST_EXIT_SPLIT
-            E u0 = F::mul(io.st_a[i], x);
-            E v0 = F::mul(io.st_b[i], F::sub(io.aux[2 * pos], u0));
+            E u0 = F::tmul(io.st_a[i], x);
+            E v0 = F::tmul(io.st_b[i], F::sub(io.aux[2 * pos], u0));
             size_t base = (pos >> log_e) << (log_e + 1);
             io.dst[base + i] = u0;
             io.dst[base + ((size_t)1 << log_e) + i] = v0;
@@ -111,16 +113,16 @@ __device__ __forceinline__ void io_store(const IoDesc<typename F::elem>& io, siz
 // the store operator of one EXTEND core followed by the load operator of the next one, applied to a value in flight
 // (ST_PLAIN / ST_SCALE / ST_AXPBY only; side output aux_out is written): used where two cores are fused in one launch
 template <class F>
-__device__ __forceinline__ typename F::elem io_mid(const IoDesc<typename F::elem>& io, size_t pos, size_t emask, const typename F::elem& x) {
+__device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t pos, size_t emask, const typename F::elem& x) {
     using E = typename F::elem;
     const size_t i = pos & emask;
     E r = x;
-    if (io.st_mode == ST_SCALE) r = F::mul(io.st_a[i], x);
+    if (io.st_mode == ST_SCALE) r = F::tmul(io.st_a[i], x);
     else if (io.st_mode == ST_AXPBY) {
-        r = F::mul_add(io.st_a[i], x, F::mul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+        r = F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
         if (io.aux_out) io.aux_out[pos] = r;
     }
-    if (io.ld_mode == LD_SCALE) r = F::mul(io.ld_tbl[i], r);
+    if (io.ld_mode == LD_SCALE) r = F::tmul(io.ld_tbl[i], r);
     return r;
 }
 
@@ -149,7 +151,7 @@ constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS
 // index computations.  No trailing barrier.
 // ---------------------------------------------------------------------------------------------
 template <class F, bool DEC>
-__device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename F::elem* __restrict__ ta, const typename F::elem* __restrict__ tb,
+__device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
                                             uint32_t lh, uint32_t npairs, uint32_t tid) {
     using E = typename F::elem;
     const uint32_t h = 1u << lh;
@@ -175,19 +177,19 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
     for (uint32_t g = tid; g < npairs; g += kBlockLds) {
         const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
         E a = a_[idx], b = a_[idx + h];
-        if (DEC) { E q1 = F::mul(tb[i], F::sub(b, a)); a_[idx] = F::mul_add(ta[i], q1, a); a_[idx + h] = q1; }
-        else { a_[idx] = F::mul_add(ta[i], b, a); a_[idx + h] = F::mul_add(tb[i], b, a); }
+        if (DEC) { E q1 = F::tmul(tb[i], F::sub(b, a)); a_[idx] = F::tmul_add(ta[i], q1, a); a_[idx + h] = q1; }
+        else { a_[idx] = F::tmul_add(ta[i], b, a); a_[idx + h] = F::tmul_add(tb[i], b, a); }
     }
 }
 
 
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<typename F::elem> io,
-                                                           const typename F::elem* __restrict__ np0,
-                                                           const typename F::elem* __restrict__ dinv,
-                                                           const typename F::elem* __restrict__ p0,
-                                                           const typename F::elem* __restrict__ p1,
-                                                           const typename F::elem* __restrict__ inner,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
+                                                           const typename F::telem* __restrict__ np0,
+                                                           const typename F::telem* __restrict__ dinv,
+                                                           const typename F::telem* __restrict__ p0,
+                                                           const typename F::telem* __restrict__ p1,
+                                                           const typename F::telem* __restrict__ inner,
                                                            uint32_t log_e, uint32_t k_first, uint32_t log_tile) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -209,13 +211,13 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         __syncthreads();
     }
     if (log_e > 0) {
-        const E c0 = inner[0], c1 = inner[1];
+        const typename F::telem c0 = inner[0], c1 = inner[1];
 #pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             E a = tile[2 * g], b = tile[2 * g + 1];
             E d = F::sub(b, a);
-            tile[2 * g] = F::mul_add(c0, d, a);
-            tile[2 * g + 1] = F::mul_add(c1, d, a);
+            tile[2 * g] = F::tmul_add(c0, d, a);
+            tile[2 * g + 1] = F::tmul_add(c1, d, a);
         }
         __syncthreads();
     }
@@ -239,7 +241,7 @@ __host__ __device__ constexpr uint32_t col_row_stride(uint32_t C) { return C + (
 
 // column-tile variant of stage_sweep: pair (row r, column cc) with partner d rows below; table entry ((r mod d) << log_hs) + c0 + cc
 template <class F, bool DEC>
-__device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const typename F::elem* __restrict__ pa, const typename F::elem* __restrict__ pb,
+__device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const typename F::telem* __restrict__ pa, const typename F::telem* __restrict__ pb,
                                                 uint32_t sft, uint32_t log_c, uint32_t log_hs, size_t c0, uint32_t npairs, uint32_t tid) {
     using E = typename F::elem;
     const uint32_t C = 1u << log_c, d = 1u << sft;
@@ -271,8 +273,8 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
         const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
         const uint32_t RS = col_row_stride<E>(C), lo = r * RS + cc, hi = lo + d * RS;
         E a = tile[lo], b = tile[hi];
-        if (DEC) { E q1 = F::mul(pb[i], F::sub(b, a)); tile[lo] = F::mul_add(pa[i], q1, a); tile[hi] = q1; }
-        else { tile[lo] = F::mul_add(pa[i], b, a); tile[hi] = F::mul_add(pb[i], b, a); }
+        if (DEC) { E q1 = F::tmul(pb[i], F::sub(b, a)); tile[lo] = F::tmul_add(pa[i], q1, a); tile[hi] = q1; }
+        else { tile[lo] = F::tmul_add(pa[i], b, a); tile[hi] = F::tmul_add(pb[i], b, a); }
     }
 }
 
@@ -285,9 +287,9 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
 // stage k: (r mod d)*hs + c_global with d = 2^(kb-k).
 // ---------------------------------------------------------------------------------------------
 template <class F, bool DECOMPOSE, int LOG_TILE_CT>     // LOG_TILE_CT > 0: log2(tile elements) known at compile time
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDesc<typename F::elem> io,
-                                                           const typename F::elem* __restrict__ ta,   // np0 | p0
-                                                           const typename F::elem* __restrict__ tb,   // dinv | p1
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDesc<F> io,
+                                                           const typename F::telem* __restrict__ ta,   // np0 | p0
+                                                           const typename F::telem* __restrict__ tb,   // dinv | p1
                                                            uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -330,9 +332,9 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
 // one HBM round trip instead of two.
 // ---------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(IoDesc<typename F::elem> io,
-                                                               const typename F::elem* __restrict__ p0, const typename F::elem* __restrict__ p1,
-                                                               const typename F::elem* __restrict__ np0, const typename F::elem* __restrict__ dinv,
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(IoDesc<F> io,
+                                                               const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                                               const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
                                                                uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -383,20 +385,23 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
 // pointwise step of those levels happens in LDS.  `LevelTables` is the per-tree table set of
 // device_tree.h (DeviceChain::Tree), indexed by log2(m).
 // ---------------------------------------------------------------------------------------------
-template <class E>
+template <class F>
 struct LevelTables {
+    using E = typename F::elem;
+    using TE = typename F::telem;
     size_t m, e; unsigned log_m;
-    E *p0[2], *p1[2], *np0[2], *dinv[2];
-    E *w[2], *winv[2];
-    E *xe, *w1x, *A1, *B1, *NB2, *C1, *D1, *xie;
-    E *inner[2];   // inner[srcpar] = {c0, c1}: the merged innermost (h = 1) decompose+recombine stage, out_j = a + c_j*(b - a)
+    // butterfly / fused pointwise constants, in the form the kernels multiply by (F::telem)
+    TE *p0[2], *p1[2], *np0[2], *dinv[2];
+    TE *w[2], *winv[2];
+    TE *xe, *w1x, *A1, *B1, *NB2, *C1, *D1, *xie;
+    TE *inner[2];   // inner[srcpar] = {c0, c1}: the merged innermost (h = 1) decompose+recombine stage, out_j = a + c_j*(b - a)
     E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
 };
 
 // every stage (decompose then recombine) of EXTEND on `len` LDS elements = len/e vectors of length e;
 // srcpar = parity of the source moiety.  Ends with a barrier.
 template <class F>
-__device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<typename F::elem>& T, int srcpar) {
+__device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<F>& T, int srcpar) {
     using E = typename F::elem;
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
@@ -408,12 +413,12 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
         __syncthreads();
     }
     if (log_e > 0) {                                    // merged innermost stage pair (h = 1)
-        const E c0 = T.inner[srcpar][0], c1 = T.inner[srcpar][1];
+        const typename F::telem c0 = T.inner[srcpar][0], c1 = T.inner[srcpar][1];
         for (uint32_t g = tid; g < npairs; g += kBlockLds) {
             E x = a[2 * g], y = a[2 * g + 1];
             E d = F::sub(y, x);
-            a[2 * g] = F::mul_add(c0, d, x);
-            a[2 * g + 1] = F::mul_add(c1, d, x);
+            a[2 * g] = F::tmul_add(c0, d, x);
+            a[2 * g + 1] = F::tmul_add(c1, d, x);
         }
         __syncthreads();
     }
@@ -427,7 +432,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
 // ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
 template <class F, int LOG_TILE>
 __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
-                                                          const LevelTables<typename F::elem>* __restrict__ trees) {
+                                                          const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, npairs = T >> 1;
@@ -440,9 +445,9 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
     for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
     __syncthreads();
     for (uint32_t l = 1; l <= log_tile; ++l) {
-        const LevelTables<E>& L = trees[l];
+        const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
-        for (uint32_t j = tid; j < T; j += kBlockLds) work[j] = F::mul(L.winv[0][j & (e - 1)], cur[j]);
+        for (uint32_t j = tid; j < T; j += kBlockLds) work[j] = F::tmul(L.winv[0][j & (e - 1)], cur[j]);
         __syncthreads();
         lds_extend_core<F>(work, T, le, L, 0);
         // combine (:155-159): block [u0|v0] + extended [U1|V1] -> interleaved evaluations; results are held in
@@ -452,8 +457,8 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
             E u0 = cur[bb + i], v0 = cur[bb + e + i], U1 = work[bb + i], V1 = work[bb + e + i];
-            ev[c] = F::mul_add(L.xe[i], v0, u0);
-            od[c] = F::mul_add(L.w1x[i], V1, F::mul(L.w[1][i], U1));
+            ev[c] = F::tmul_add(L.xe[i], v0, u0);
+            od[c] = F::tmul_add(L.w1x[i], V1, F::tmul(L.w[1][i], U1));
         }
         __syncthreads();
 #pragma unroll
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
 // DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
 template <class F, int LOG_TILE>
 __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
-                                                         const LevelTables<typename F::elem>* __restrict__ trees) {
+                                                         const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, nh = T >> 1;
@@ -484,24 +489,24 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
     for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
     __syncthreads();
     for (uint32_t l = log_tile; l >= 1; --l) {
-        const LevelTables<E>& L = trees[l];
+        const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
-        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::mul(L.A1[g & (e - 1)], cur[2 * g]);
+        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::tmul(L.A1[g & (e - 1)], cur[2 * g]);
         __syncthreads();
         lds_extend_core<F>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += kBlockLds) {
             uint32_t i = g & (e - 1);
-            E r = F::mul_add(L.NB2[i], G[g], F::mul(L.B1[i], cur[2 * g + 1]));
+            E r = F::tmul_add(L.NB2[i], G[g], F::tmul(L.B1[i], cur[2 * g + 1]));
             G[g] = r; H[g] = r;
         }
         __syncthreads();
         lds_extend_core<F>(G, nh, le, L, 1);
-        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::mul(L.C1[g & (e - 1)], G[g]);
+        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::tmul(L.C1[g & (e - 1)], G[g]);
         __syncthreads();
         lds_extend_core<F>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += kBlockLds) {
             uint32_t i = g & (e - 1);
-            G[g] = F::mul_add(L.NB2[i], G[g], F::mul(L.D1[i], H[g]));
+            G[g] = F::tmul_add(L.NB2[i], G[g], F::tmul(L.D1[i], H[g]));
         }
         __syncthreads();
         lds_extend_core<F>(G, nh, le, L, 1);
@@ -509,8 +514,8 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1);
-            u[c] = F::mul(L.w[0][i], G[g]);
-            v[c] = F::mul(L.xie[i], F::sub(cur[2 * g], u[c]));
+            u[c] = F::tmul(L.w[0][i], G[g]);
+            v[c] = F::tmul(L.xie[i], F::sub(cur[2 * g], u[c]));
         }
         __syncthreads();
 #pragma unroll
@@ -530,11 +535,11 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
 template <class F>
 __global__ __launch_bounds__(kBlock) void k_scale_by_table(typename F::elem* dst,  // may alias src
                                                             const typename F::elem* src,
-                                                            const typename F::elem* __restrict__ tbl,
+                                                            const typename F::telem* __restrict__ tbl,
                                                             size_t tbl_mask, size_t n, uint32_t tstride, uint32_t toff) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
-    dst[g] = F::mul(tbl[(g & tbl_mask) * tstride + toff], src[g]);
+    dst[g] = F::tmul(tbl[(g & tbl_mask) * tstride + toff], src[g]);
 }
 
 // dst[b*m + 2i]   = u0[i] + xe[i]*v0[i]                (src block  = [u0 | v0])
@@ -543,9 +548,9 @@ template <class F>
 __global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __restrict__ dst,
                                                            const typename F::elem* __restrict__ src,
                                                            const typename F::elem* __restrict__ work,
-                                                           const typename F::elem* __restrict__ xe,
-                                                           const typename F::elem* __restrict__ w1,
-                                                           const typename F::elem* __restrict__ w1x,
+                                                           const typename F::telem* __restrict__ xe,
+                                                           const typename F::telem* __restrict__ w1,
+                                                           const typename F::telem* __restrict__ w1x,
                                                            uint32_t log_e, size_t npairs) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= npairs) return;
@@ -554,8 +559,8 @@ __global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __re
     size_t base = (g >> log_e) << (log_e + 1);
     typename F::elem u0 = src[base + i], v0 = src[base + e + i];
     typename F::elem U1 = work[base + i], V1 = work[base + e + i];
-    typename F::elem even = F::mul_add(xe[i], v0, u0);
-    typename F::elem odd = F::mul_add(w1x[i], V1, F::mul(w1[i], U1));
+    typename F::elem even = F::tmul_add(xe[i], v0, u0);
+    typename F::elem odd = F::tmul_add(w1x[i], V1, F::tmul(w1[i], U1));
     dst[base + 2 * i] = even;
     dst[base + 2 * i + 1] = odd;
 }

@@ -218,6 +218,174 @@ def gen_reduce():
     return L
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Two-table variant: the table constant is stored as the pair (t, u = t * 2^128 mod p), so that
+#   t*x = t*x_lo + u*x_hi  (x = x_lo + 2^128 x_hi)
+# is a sum of two 256x128-bit products: still 64 mads, but the result has 12 words (+1 bit) instead of 16, the fold
+# multiplies 4 high words instead of 8, and the value after the fold exceeds 2^256 only with probability ~2^-94, so the
+# second fold moves into the (wave-uniform, essentially never taken) canonicalisation branch.
+def gen_product2(has_c):
+    npair = 11
+    nprod = {k: 2 * min(k + 1, 4, 11 - k) for k in range(npair)}
+    seen = {k: 0 for k in range(npair)}
+    ex_live = {k: False for k in range(npair)}
+    lines = []
+    if has_c:
+        lines += ["        const uint64_t c%d = (uint64_t)c.l[%d] | ((uint64_t)c.l[%d] << 32);" % (q, 2 * q, 2 * q + 1) for q in range(4)]
+    lines.append("        uint64_t E0, E1, E2, E3, E4, E5, O0, O1, O2, O3, O4;")
+    lines.append("        uint32_t " + ", ".join(f"X{k}" for k in range(npair)) + ";")
+    for part in range(2):
+        tn = "t" if part == 0 else "u"
+        ks = list(range(npair))
+        outs, pair_idx, ex_idx = [], {}, {}
+        for k in ks:
+            pair_idx[k] = len(outs); outs.append((pair_name(k), "=&v" if seen[k] == 0 else "+v"))
+        for k in ks:
+            will = (part == 1) or nprod[k] // 2 >= 2 or (has_c and k % 2 == 0 and k < 8)
+            if will:
+                ex_idx[k] = len(outs); outs.append((f"X{k}", "+v" if ex_live[k] else "=&v"))
+        nout = len(outs)
+        in_names, tpos, xpos, c_idx = [], {}, {}, {}
+        for i in range(8):
+            tpos[i] = nout + len(in_names); in_names.append(f"{tn}.l[{i}]")
+        for j in range(4):
+            xpos[j] = nout + len(in_names); in_names.append(f"x.l[{4 * part + j}]")
+        if has_c and part == 0:
+            for q in range(4):
+                c_idx[2 * q] = nout + len(in_names); in_names.append(f"c{q}")
+        body = []
+        for i in range(8):
+            for j in range(4):
+                k = i + j
+                first = seen[k] == 0
+                P = pair_idx[k]
+                if first and k in c_idx:
+                    body.append(f"v_mad_u64_u32 %{P}, vcc, %{tpos[i]}, %{xpos[j]}, %{c_idx[k]}")
+                elif first:
+                    body.append(f"v_mad_u64_u32 %{P}, vcc, %{tpos[i]}, %{xpos[j]}, 0")
+                else:
+                    body.append(f"v_mad_u64_u32 %{P}, vcc, %{tpos[i]}, %{xpos[j]}, %{P}")
+                if (not first) or (k in c_idx):
+                    xi = ex_idx[k]
+                    if not ex_live[k]:
+                        body.append(f"v_addc_co_u32_e64 %{xi}, vcc, 0, 0, vcc")
+                    else:
+                        body.append(f"v_addc_co_u32_e32 %{xi}, vcc, 0, %{xi}, vcc")
+                    ex_live[k] = True
+                seen[k] += 1
+        asm = "\\n\\t".join(body)
+        outs_s = ", ".join(f'"{c}"({n})' for n, c in outs)
+        ins_s = ", ".join(f'"v"({n})' for n in in_names)
+        lines.append(f'        asm("{asm}"\n            : {outs_s}\n            : {ins_s}\n            : "vcc");')
+    assert all(seen[k] == nprod[k] for k in range(npair)) and all(ex_live.values())
+    return lines
+
+
+def gen_combine2():
+    """W = E + (O<<32) + X (13 words s0..s12, s12 <= 1), then the four mads hi*977 (words 8..11)."""
+    L = []
+    e = [f"(uint32_t)(E{k // 2}{' >> 32' if k % 2 else ''})" for k in range(12)]
+    o = {k: f"(uint32_t)(O{(k - 1) // 2}{' >> 32' if (k - 1) % 2 else ''})" for k in range(1, 11)}
+    xs = {k + 2: f"X{k}" for k in range(11)}
+    L.append("        uint32_t s0 = " + e[0] + ";")
+    L.append("        uint32_t " + ", ".join(f"s{k}" for k in range(1, 13)) + ";")
+    L.append("        uint64_t ue0, ue1, uo0, uo1;")
+    L.append("        const uint32_t k977 = 977u;")
+    outs = [f'"=&v"(s{k})' for k in range(1, 13)]                      # %0..%11 = s1..s12
+    hi_names = ["ue0", "uo0", "ue1", "uo1"]                            # s8*977 (words 0,1), s9*977 (1,2), s10*977 (2,3), s11*977 (3,4)
+    outs += [f'"=&v"({n})' for n in hi_names]                          # %12..%15
+    nout = len(outs)
+    ins, pos = [], {}
+
+    def inp(expr, cons="v"):
+        if expr not in pos:
+            pos[expr] = nout + len(ins); ins.append(f'"{cons}"({expr})')
+        return f"%{pos[expr]}"
+    body = []
+    for k in range(1, 13):                                              # chain 1
+        so = k - 1
+        if k == 1:
+            body.append(f"v_add_co_u32_e32 %{so}, vcc, {inp(e[k])}, {inp(o[k])}")
+        elif k <= 10:
+            body.append(f"v_addc_co_u32_e32 %{so}, vcc, {inp(e[k])}, {inp(o[k])}, vcc")
+        elif k == 11:
+            body.append(f"v_addc_co_u32_e32 %{so}, vcc, 0, {inp(e[k])}, vcc")
+        else:
+            body.append(f"v_addc_co_u32_e64 %{so}, vcc, 0, 0, vcc")
+    for k in range(2, 13):                                              # chain 2
+        so = k - 1
+        if k == 2:
+            body.append(f"v_add_co_u32_e32 %{so}, vcc, {inp(xs[k])}, %{so}")
+        else:
+            body.append(f"v_addc_co_u32_e32 %{so}, vcc, {inp(xs[k])}, %{so}, vcc")
+    kk = inp("k977", "s")
+    for j in range(4):
+        body.append(f"v_mad_u64_u32 %{12 + j}, vcc, %{7 + j}, {kk}, 0")  # s[8+j] is output %(8+j-1)
+    L.append('        asm("' + "\\n\\t".join(body) + f'"\n            : {", ".join(outs)}\n            : {", ".join(ins)}\n            : "vcc");')
+    return L
+
+
+def gen_reduce2():
+    """V = lo + hi*(2^32 + 977), hi = s8..s12 (129 bits): H = hi*977 + (hi << 32) has 6 words, V = lo + H carries out of
+    2^256 only if lo >= 2^256 - 2^163; that case and r >= p share the canonicalisation branch."""
+    L = []
+    L.append("        uint32_t h1, h2, h3, h4, h5, m4;")
+    L.append("        uint32_t r0, r1, r2, r3, r4, r5, r6, r7, q0, q1, q2, q3, q4, q5, q6, q7;")
+    L.append("        uint64_t ovf, ovf2;")
+    ue = [f"(uint32_t)(ue{k // 2}{' >> 32' if k % 2 else ''})" for k in range(4)]           # word k, k = 0..3
+    uo = {k: f"(uint32_t)(uo{(k - 1) // 2}{' >> 32' if (k - 1) % 2 else ''})" for k in range(1, 5)}  # word k, k = 1..4
+    out_names = ["h1", "h2", "h3", "h4", "h5", "m4"] + [f"r{k}" for k in range(8)] + [f"q{k}" for k in range(8)]
+    outs = [f'"=&v"({n})' for n in out_names] + ['"=&s"(ovf)', '"=&s"(ovf2)']
+    H = {k: k - 1 for k in range(1, 6)}; M4 = 5
+    Rr = {k: 6 + k for k in range(8)}; Q = {k: 14 + k for k in range(8)}; OVF, OVF2 = 22, 23
+    nout = len(outs)
+    ins, pos = [], {}
+
+    def inp(expr, cons="v"):
+        if expr not in pos:
+            pos[expr] = nout + len(ins); ins.append(f'"{cons}"({expr})')
+        return f"%{pos[expr]}"
+    body = []
+    kk = inp("k977", "s")
+    # m4 = s12*977 + (word 4 of UO): both tiny
+    body.append(f"v_mad_u32_u24 %{M4}, {inp('s12')}, {kk}, {inp(uo[4])}")
+    # chain A: h[1..5] = (hi << 32) + (UO << 32) + m4 at word 4
+    body.append(f"v_add_co_u32_e32 %{H[1]}, vcc, {inp('s8')}, {inp(uo[1])}")
+    body.append(f"v_addc_co_u32_e32 %{H[2]}, vcc, {inp('s9')}, {inp(uo[2])}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[3]}, vcc, {inp('s10')}, {inp(uo[3])}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[4]}, vcc, {inp('s11')}, %{M4}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[5]}, vcc, 0, {inp('s12')}, vcc")
+    # chain B: h += UE (words 0..3; word 0 of H is ue[0] itself)
+    body.append(f"v_add_co_u32_e32 %{H[1]}, vcc, {inp(ue[1])}, %{H[1]}")
+    body.append(f"v_addc_co_u32_e32 %{H[2]}, vcc, {inp(ue[2])}, %{H[2]}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[3]}, vcc, {inp(ue[3])}, %{H[3]}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[4]}, vcc, 0, %{H[4]}, vcc")
+    body.append(f"v_addc_co_u32_e32 %{H[5]}, vcc, 0, %{H[5]}, vcc")
+    # chain C: r = lo + H
+    body.append(f"v_add_co_u32_e32 %{Rr[0]}, vcc, {inp('s0')}, {inp(ue[0])}")
+    for k in range(1, 6):
+        body.append(f"v_addc_co_u32_e32 %{Rr[k]}, vcc, {inp(f's{k}')}, %{H[k]}, vcc")
+    for k in range(6, 8):
+        body.append(f"v_addc_co_u32_e32 %{Rr[k]}, vcc, 0, {inp(f's{k}')}, vcc")
+    body.append(f"s_mov_b64 %{OVF}, vcc")
+    # canonicalise (same contract as the 16-word variant): take q = r + (2^32 + 977) if the value passed 2^256 or r >= p
+    body.append(f"v_cmp_eq_u32_e32 vcc, -1, %{Rr[7]}")
+    body.append(f"s_or_b64 %{OVF2}, %{OVF}, vcc")
+    body.append("s_cbranch_scc0 .Lecfft_canon2_done_%=")
+    body.append(f"v_add_co_u32_e32 %{Q[0]}, vcc, 0x3d1, %{Rr[0]}")
+    body.append(f"v_addc_co_u32_e32 %{Q[1]}, vcc, 1, %{Rr[1]}, vcc")
+    for k in range(2, 8):
+        body.append(f"v_addc_co_u32_e32 %{Q[k]}, vcc, 0, %{Rr[k]}, vcc")
+    body.append(f"s_or_b64 %{OVF2}, %{OVF}, vcc")
+    for k in range(8):
+        body.append(f"v_cndmask_b32_e64 %{Rr[k]}, %{Rr[k]}, %{Q[k]}, %{OVF2}")
+    body.append(".Lecfft_canon2_done_%=:")
+    L.append('        asm("' + "\\n\\t".join(body) + '"\n            : ' + ", ".join(outs) + "\n            : " + ", ".join(ins) + '\n            : "vcc", "scc");')
+    L.append("        elem r; r.l[0] = r0; r.l[1] = r1; r.l[2] = r2; r.l[3] = r3; r.l[4] = r4; r.l[5] = r5; r.l[6] = r6; r.l[7] = r7;")
+    L.append("        return r;")
+    return L
+
+
 def main():
     out = ["// GENERATED by tools/gen_mulmod_asm.py — do not edit.  Included inside struct ecfft::Secp256k1 (device only).", ""]
     for has_c in (False, True):
@@ -228,6 +396,16 @@ def main():
         out += prod
         out += gen_combine(ex_live)
         out += gen_reduce()
+        out.append("    }")
+        out.append("")
+    for has_c in (False, True):
+        name = "mul2_add_gfx950" if has_c else "mul2_gfx950"
+        sig = "const elem& t, const elem& u, const elem& x" + (", const elem& c" if has_c else "")
+        out.append(f"    // (t, u = t * 2^128 mod p) * x" + (" + c" if has_c else ""))
+        out.append(f"    __device__ static inline elem {name}({sig}) {{")
+        out += gen_product2(has_c)
+        out += gen_combine2()
+        out += gen_reduce2()
         out.append("    }")
         out.append("")
     with open(OUT, "w") as f:

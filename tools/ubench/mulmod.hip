@@ -25,6 +25,14 @@ __global__ __launch_bounds__(256) void k_chain(const Fe256* t, const Fe256* c, F
     if (g == 0) { g_cycles[0] = t1 - t0; }
 }
 
+__global__ __launch_bounds__(256) void k_chain2(const Fe256* t, const Fe256* u, const Fe256* c, Fe256* x) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    Fe256 tv = t[g], uv = u[g], cv = c[g], xv = x[g];
+#pragma unroll 1
+    for (int i = 0; i < ITER; ++i) xv = F::mul2_add(tv, uv, xv, cv);
+    x[g] = xv;
+}
+
 int main() {
     const int blocks = 256 * 8, n = blocks * 256;
     std::vector<Fe256> ht(n), hc(n), hx(n);
@@ -49,6 +57,30 @@ int main() {
         if (!F::eq(v, out[i])) ++bad;
     }
     printf("verify vs host (4096 lanes x %d iters): %s\n", ITER, bad ? "MISMATCH" : "ok");
+    {   // two-table variant: u = t * 2^128 mod p
+        std::vector<Fe256> hu(n);
+        Fe256 k128 = F::zero(); k128.l[4] = 1;
+        for (int i = 0; i < n; ++i) hu[i] = F::mul(ht[i], k128);
+        Fe256* du; hipMalloc(&du, n * 32);
+        hipMemcpy(du, hu.data(), n * 32, hipMemcpyHostToDevice);
+        hipMemcpy(dx, hx.data(), n * 32, hipMemcpyHostToDevice);
+        k_chain2<<<blocks, 256>>>(dt, du, dc, dx);
+        std::vector<Fe256> out2(n);
+        hipMemcpy(out2.data(), dx, n * 32, hipMemcpyDeviceToHost);
+        int bad2 = 0;
+        for (int i = 0; i < n; ++i) if (!F::eq(out2[i], out[i])) ++bad2;
+        printf("two-table variant vs one-table (all %d lanes): %s (%d)\n", n, bad2 ? "MISMATCH" : "ok", bad2);
+        bad += bad2;
+        hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
+        for (int wpb = 4; wpb <= 8; wpb += 4) {
+            int grid = 256 * wpb; float best = 1e30f;
+            for (int r = 0; r < 5; ++r) {
+                (void)hipEventRecord(f0); k_chain2<<<grid, 256>>>(dt, du, dc, dx); (void)hipEventRecord(f1); (void)hipEventSynchronize(f1);
+                float ms; (void)hipEventElapsedTime(&ms, f0, f1); if (ms < best) best = ms;
+            }
+            printf("two-table waves/SIMD %d: %.3f ms, %.3e field-mul/s chip-wide\n", wpb, best, (double)grid * 256 * ITER / (best * 1e-3));
+        }
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int wpb = 1; wpb <= 8; ++wpb) {           // resident 256-thread blocks per CU (4 waves each => wpb waves per SIMD)
         int grid = 256 * wpb;
