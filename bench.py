@@ -68,6 +68,40 @@ def cpu_baseline(field, log_n):
             "host_cpu": _cpu_name()}
 
 
+def _socket_cores():
+    """physical cores of one socket that this process may run on (falls back to the affinity mask size)"""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("cpu cores"):
+                    return max(1, min(avail, int(line.split(":", 1)[1])))
+    except (OSError, ValueError):
+        pass
+    return max(1, avail)
+
+
+def cpu_baseline_socket(field, log_n):
+    """single-socket figure: the same single-threaded oracle on every physical core of one socket at once,
+    one independent polynomial per thread (the reference has no threading of its own; this is its best case on a socket)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    F = oracle.field(field)
+    n = 1 << log_n
+    t = F.build_fftree(n)
+    cores = _socket_cores()
+    inputs = [synth(field, n, 0xC0FFEE + 1 + i) for i in range(cores)]
+
+    def one(c):                      # ctypes releases the GIL inside the C calls
+        return np.array_equal(t.exit(t.enter(c)), c)
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        t0 = time.perf_counter(); ok = list(ex.map(one, inputs)); dt = time.perf_counter() - t0
+    assert all(ok)
+    we, wx = w_mul(n)
+    return {"value": cores * (we + wx) / dt, "unit": "field-mul/s", "cores": cores, "kind": "port",
+            "sample": f"{field} n=2^{log_n}: {cores} independent ENTER+EXIT round trips, one per thread, {dt:.3f}s wall", "host_cpu": _cpu_name()}
+
+
 def _cpu_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -236,6 +270,8 @@ def main():
         if world == 1 and args.cpu_log_n > 0:
             out["cpu_baseline"] = cpu_baseline(args.field, args.cpu_log_n)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["cpu_baseline_socket"] = cpu_baseline_socket(args.field, args.cpu_log_n)
+            out["gpu_over_cpu_socket"] = value / out["cpu_baseline_socket"]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

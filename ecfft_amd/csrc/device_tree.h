@@ -126,10 +126,17 @@ public:
                 hipEventCreateWithFlags(&ev_join_[nside_], hipEventDisableTiming) != hipSuccess) break;
         }
         trees_.assign(L_ + 1, Tree{});
+        {   // ~32 m temporaries are alive while T_m is built; one slab instead of ~80 hipMalloc/hipFree pairs per tree
+            size_t want = 40 * N_ + 16384, cap_bytes = (size_t)16 << 30;
+            if (want * sizeof(E) > cap_bytes) want = cap_bytes / sizeof(E);
+            if (hipMalloc(&slab_, want * sizeof(E)) == hipSuccess) slab_cap_ = want; else { (void)hipGetLastError(); slab_ = nullptr; slab_cap_ = 0; }
+            slab_used_ = 0;
+        }
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
         }
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
+        if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
         for (void* p : temps_) (void)hipFree(p);
         temps_.clear();
         ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
@@ -152,6 +159,9 @@ public:
     // ------------------------------------------------------------------------------------------
 #ifndef ECFFT_LOG_TILE_BYTES
 #define ECFFT_LOG_TILE_BYTES 15
+#endif
+#ifndef ECFFT_CT_ALL
+#define ECFFT_CT_ALL 0      // 1: compile-time tile sizes for every field (default: 4-byte fields only)
 #endif
     static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
 #ifndef ECFFT_COL_STAGES
@@ -221,7 +231,7 @@ public:
                 unsigned nst = le - k_first;
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
-                if (log_tile == kLogTileMax && sizeof(E) == 4)   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
+                if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
                 else
@@ -232,7 +242,7 @@ public:
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
-                const bool ct = (log_ct == kLogColTileMax && sizeof(E) == 4);
+                const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
                 dim3 grid((unsigned)(total >> log_ct)); size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R);
                 if (P.kind == 0) {
                     if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
@@ -598,7 +608,11 @@ private:
         foreach_n(s, n, [=] __device__(size_t i) { d[i] = F::to_table(src[i]); });
         return d;
     }
+    // construction temporaries come from one slab (bump-allocated, reset after every tree); anything that does not fit,
+    // and every temporary of the public algorithm wrappers, is an individual allocation released by finish_api()
     E* temp(size_t n) {
+        size_t a = (n + 7) & ~(size_t)7;
+        if (slab_ && slab_used_ + a <= slab_cap_) { E* q = slab_ + slab_used_; slab_used_ += a; return q; }
         void* p = nullptr;
         if (hipMalloc(&p, (n ? n : 1) * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: temp alloc failed\n"); abort(); }
         temps_.push_back(p); return (E*)p;
@@ -607,6 +621,7 @@ private:
         for (void* p : temps_) (void)hipFree(p);
         temps_.clear();
         if (arena_) (void)hipFree(arena_);
+        if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
         if (scratch_) (void)hipFree(scratch_);
         if (d_trees_) (void)hipFree(d_trees_);
         d_trees_ = nullptr;
@@ -886,6 +901,7 @@ private:
         if (hipStreamSynchronize(s) != hipSuccess) return false;
         for (void* p : temps_) (void)hipFree(p);
         temps_.clear();
+        slab_used_ = 0;
         return true;
     }
 
@@ -894,6 +910,7 @@ private:
     size_t N_ = 0; unsigned L_ = 0; int device_ = 0;
     E* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
     E* f_ = nullptr; E* den_ = nullptr; E* scratch_ = nullptr; size_t scratch_cap_ = 0;
+    E* slab_ = nullptr; size_t slab_cap_ = 0, slab_used_ = 0;
     std::vector<Tree> trees_;
     Tree* d_trees_ = nullptr;
     std::vector<void*> temps_;
