@@ -232,10 +232,10 @@ public:
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
                 if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
-                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
                 else
-                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, 0>), dim3((unsigned)(total >> log_tile)), dim3(kBlockLds),
+                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, 0>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
             } else {
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;           // column tiles may be larger than row tiles

@@ -139,6 +139,10 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
 #define ECFFT_BLOCK_LDS 512
 #endif
 constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS-fused kernels
+#ifndef ECFFT_BLOCK_ROW
+#define ECFFT_BLOCK_ROW ECFFT_BLOCK_LDS
+#endif
+constexpr int kBlockRow = ECFFT_BLOCK_ROW;   // ... of the row kernel (k_stages_lds)
 #ifndef ECFFT_MIN_WAVES
 #define ECFFT_MIN_WAVES 4                    // waves per SIMD the register allocator must leave room for
 #endif
@@ -150,14 +154,14 @@ constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS
 // their partners and their table entries are then contiguous and 16-byte aligned): 4x fewer memory instructions and
 // index computations.  No trailing barrier.
 // ---------------------------------------------------------------------------------------------
-template <class F, bool DEC>
+template <class F, bool DEC, int BLK = kBlockLds>
 __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
                                             uint32_t lh, uint32_t npairs, uint32_t tid) {
     using E = typename F::elem;
     const uint32_t h = 1u << lh;
     if constexpr (sizeof(E) == 4) {
         if (lh >= 2 && (npairs & 3u) == 0) {
-            for (uint32_t g4 = tid; g4 < (npairs >> 2); g4 += kBlockLds) {
+            for (uint32_t g4 = tid; g4 < (npairs >> 2); g4 += BLK) {
                 const uint32_t g = g4 << 2, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
                 uint4 va = *reinterpret_cast<const uint4*>(a_ + idx), vb = *reinterpret_cast<const uint4*>(a_ + idx + h);
                 const uint4 v0 = *reinterpret_cast<const uint4*>(ta + i), v1 = *reinterpret_cast<const uint4*>(tb + i);
@@ -174,7 +178,7 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
             return;
         }
     }
-    for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+    for (uint32_t g = tid; g < npairs; g += BLK) {
         const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
         E a = a_[idx], b = a_[idx + h];
         if (DEC) { E q1 = F::tmul(tb[i], F::sub(b, a)); a_[idx] = F::tmul_add(ta[i], q1, a); a_[idx + h] = q1; }
@@ -184,7 +188,7 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
 
 
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
+__global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
                                                            const typename F::telem* __restrict__ np0,
                                                            const typename F::telem* __restrict__ dinv,
                                                            const typename F::telem* __restrict__ p0,
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const size_t base = (size_t)blockIdx.x << log_tile;
     const size_t e = (size_t)1 << log_e, emask = e - 1;
 #pragma unroll
-    for (uint32_t j = tid; j < T; j += kBlockLds) tile[j] = io_load<F>(io, base + j, emask);
+    for (uint32_t j = tid; j < T; j += kBlockRow) tile[j] = io_load<F>(io, base + j, emask);
     __syncthreads();
     const uint32_t npairs = T >> 1;
     // stages k_first .. log_e-2 (h >= 2); the two innermost stages (decompose h=1, recombine h=1) act on the
@@ -207,13 +211,13 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     for (uint32_t k = k_first; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        stage_sweep<F, true>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid);
+        stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
     }
     if (log_e > 0) {
         const typename F::telem c0 = inner[0], c1 = inner[1];
 #pragma unroll
-        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+        for (uint32_t g = tid; g < npairs; g += kBlockRow) {
             E a = tile[2 * g], b = tile[2 * g + 1];
             E d = F::sub(b, a);
             tile[2 * g] = F::tmul_add(c0, d, a);
@@ -223,11 +227,11 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     }
     for (uint32_t k = k_inner; k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        stage_sweep<F, false>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
+        stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
     }
 #pragma unroll
-    for (uint32_t j = tid; j < T; j += kBlockLds) io_store<F>(io, base + j, log_e, tile[j]);
+    for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
 }
 
 #ifndef ECFFT_COL_PAD
