@@ -43,6 +43,16 @@ KERNEL_BODY(k_lshl_add_u32, DECL32, ALL8(OP4, "v_lshl_add_u32"), FOLD32)
 KERNEL_BODY(k_alignbit, DECL32, ALL8(OP4, "v_alignbit_b32"), FOLD32)
 #define OPCO(c) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc" : "+v"(c) : "v"(a), "v"(b) : "vcc");
 KERNEL_BODY(k_add_co_addc_pair, DECL32, OPCO(c0) OPCO(c1) OPCO(c2) OPCO(c3) OPCO(c4) OPCO(c5) OPCO(c6) OPCO(c7), FOLD32)
+#define OPCO64Z(c) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32_e64 %0, vcc, 0, 0, vcc" : "+v"(c) : "v"(a) : "vcc");
+KERNEL_BODY(k_addc_e64_zero, DECL32, OPCO64Z(c0) OPCO64Z(c1) OPCO64Z(c2) OPCO64Z(c3) OPCO64Z(c4) OPCO64Z(c5) OPCO64Z(c6) OPCO64Z(c7), FOLD32)
+#define OPCO32Z(c) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %2, vcc" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+KERNEL_BODY(k_addc_e32_zero, DECL32, OPCO32Z(c0) OPCO32Z(c1) OPCO32Z(c2) OPCO32Z(c3) OPCO32Z(c4) OPCO32Z(c5) OPCO32Z(c6) OPCO32Z(c7), FOLD32)
+#define OPCND(c) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(c) : "v"(a) : "s10", "s11");
+KERNEL_BODY(k_cndmask_e64, DECL32, OPCND(c0) OPCND(c1) OPCND(c2) OPCND(c3) OPCND(c4) OPCND(c5) OPCND(c6) OPCND(c7), FOLD32)
+#define OPMADCO(c) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32_e32 %3, vcc, 0, %3, vcc" : "+v"(c), "+v"(x) : "v"(a), "v"(b) : "vcc");
+KERNEL_BODY(k_mad_addc_pair, DECL64 uint32_t x = t;, OPMADCO(c0) OPMADCO(c1) OPMADCO(c2) OPMADCO(c3) OPMADCO(c4) OPMADCO(c5) OPMADCO(c6) OPMADCO(c7), (FOLD64) ^ x)
+#define OPLA64(c) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(c) : "v"(c7));
+KERNEL_BODY(k_lshl_add_u64, DECL64, OPLA64(c0) OPLA64(c1) OPLA64(c2) OPLA64(c3) OPLA64(c4) OPLA64(c5) OPLA64(c6) c7 += a;, FOLD64)
 #define OPMADU16(c) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 KERNEL_BODY(k_mad_u32_u16, DECL32, OPMADU16(c0) OPMADU16(c1) OPMADU16(c2) OPMADU16(c3) OPMADU16(c4) OPMADU16(c5) OPMADU16(c6) OPMADU16(c7), FOLD32)
 #define OPDOT4(c) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -83,6 +93,11 @@ int main() {
     run("v_lshl_add_u32", k_lshl_add_u32, d_out, 8);
     run("v_alignbit_b32", k_alignbit, d_out, 8);
     run("add_co+addc (2 inst)", k_add_co_addc_pair, d_out, 16);
+    run("add_co+addc_e64 0,0 (2)", k_addc_e64_zero, d_out, 16);
+    run("add_co+addc_e32 0,v (2)", k_addc_e32_zero, d_out, 16);
+    run("v_cndmask_b32_e64", k_cndmask_e64, d_out, 8);
+    run("mad_u64+addc (2 inst)", k_mad_addc_pair, d_out, 16);
+    run("v_lshl_add_u64 (7)", k_lshl_add_u64, d_out, 7);
     run("v_mul_lo_u32", k_mul_lo_u32, d_out, 8);
     run("v_mul_hi_u32", k_mul_hi_u32, d_out, 8);
     run("v_mad_u64_u32", k_mad_u64_u32, d_out, 8);
