@@ -218,6 +218,23 @@ def test_full_size_properties(gpu, gpu_tree, oracle_mod, field, log_n):
     assert np.array_equal(t.extend(el[1::2].copy(), gpu.Moiety.S0), el[0::2])
 
 
+def test_config4_extend_2e22(gpu, gpu_tree, oracle_mod):
+    """BASELINE.json configs[3] size: EXTEND of e = 2^22 secp256k1 evaluations (on T_{2^23}), both directions, against
+    values pinned by naive Horner evaluation (oracle) at individual leaves."""
+    F = oracle_mod.field("secp256k1")
+    e = 1 << 22
+    t = gpu_tree("secp256k1", 2 * e)
+    c = rand_elems(F, 2 * e, 41)
+    c[e:] = 0                                     # degree < e: determined by its values on either moiety
+    ev = t.enter(c)
+    leaves = t.leaves()
+    idx = np.array([0, 1, 2, 3, e - 1, e, 2 * e - 2, 2 * e - 1, 1234567, 7654321])
+    assert np.array_equal(ev[idx], F.horner(c[:e], leaves[idx]))
+    s0, s1 = ev[0::2].copy(), ev[1::2].copy()
+    assert np.array_equal(t.extend(s0, gpu.Moiety.S1), s1)
+    assert np.array_equal(t.extend(s1, gpu.Moiety.S0), s0)
+
+
 def test_one_context_from_two_threads_and_streams(gpu, gpu_tree, oracle_tree):
     """a context serialises its transforms: two host threads driving the SAME context on different torch streams must
     not corrupt each other's scratch (host mutex for the enqueues + HIP event across streams, ecfft_hip.h 'Threading')"""
