@@ -9,7 +9,9 @@
 //   w[s], winv[s]                   e entries   (normalisation weights of the parity's leaves)
 //   xe, w1x                         e entries   ENTER combine
 //   A1, B1, NB2, C1, D1, xie        e entries   EXIT pointwise steps with every inverse pre-fused
-// All tables are PLAIN residues; user data stays in the crate's Montgomery form (field_secp256k1.h).
+// All tables are PLAIN residues; user data stays in the crate's Montgomery form (field_secp256k1.h).  The tables above are
+// stored as F::telem — for secp256k1 the pair (t, t*2^128 mod p) that the 12-word multiply wants — and are written by
+// to_tables() from plain temporaries; the reference's own tables (xnn, z*) stay plain F::elem arrays.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
