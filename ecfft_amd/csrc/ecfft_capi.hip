@@ -280,7 +280,7 @@ int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, co
 template <class F>
 int run_selftest(int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
     using E = typename F::elem;
-    if (!a || !b || !out || (op == 0 && !c) || op < 0 || op > 3) return ECFFT_ERR_BAD_ARG;
+    if (!a || !b || !out || ((op == 0 || op == 4) && !c) || op < 0 || op > 5) return ECFFT_ERR_BAD_ARG;
     if (!have_device(device) || hipSetDevice(device) != hipSuccess) return ECFFT_ERR_HIP;
     E *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
     size_t bytes = n * sizeof(E);
@@ -294,7 +294,9 @@ int run_selftest(int op, const void* a, const void* b, const void* c, void* out,
             if (op == 0) r = F::mul_add(pa[i], pb[i], pc[i]);
             else if (op == 1) r = F::mul(pa[i], pb[i]);
             else if (op == 2) r = F::sub(pa[i], pb[i]);
-            else r = F::add(pa[i], pb[i]);
+            else if (op == 3) r = F::add(pa[i], pb[i]);
+            else if (op == 4) r = F::tmul_add(F::to_table(pa[i]), pb[i], pc[i]);
+            else r = F::tmul(F::to_table(pa[i]), pb[i]);
             po[i] = r;
         });
         ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) == hipSuccess;

@@ -31,8 +31,18 @@ struct M31 {
     __host__ __device__ static inline elem mul(elem t, elem x) { return red64((uint64_t)t * x); }
     __host__ __device__ static inline elem mul_add(elem t, elem x, elem c) { return red64((uint64_t)t * x + c); }
     __host__ __device__ static inline telem to_table(elem t) { return t; }
-    __host__ __device__ static inline elem tmul(telem t, elem x) { return mul(t, x); }
-    __host__ __device__ static inline elem tmul_add(telem t, elem x, elem c) { return mul_add(t, x, c); }
+    // Table x data inside the butterfly kernels works on the LAZY range [0, p] (p itself = a second representative of 0):
+    // for t <= p-1 and x, c <= p the product t*x + c <= p^2 < 2^62, so lo + hi <= 2^32 - 2 and the second fold lands in
+    // [0, p] again — the final conditional subtract of the canonical reduction (2 of 9 instructions) is dropped.  sub()
+    // maps [0, p] x [0, p] into [0, p] as written.  Every value that leaves a kernel for HBM goes through canon().
+    __host__ __device__ static inline elem red64_lazy(uint64_t t) {
+        uint32_t lo = (uint32_t)t & P, hi = (uint32_t)(t >> 31);
+        uint32_t r = lo + hi;
+        return (r & P) + (r >> 31);
+    }
+    __host__ __device__ static inline elem tmul(telem t, elem x) { return red64_lazy((uint64_t)t * x); }
+    __host__ __device__ static inline elem tmul_add(telem t, elem x, elem c) { return red64_lazy((uint64_t)t * x + c); }
+    __host__ __device__ static inline elem canon(elem x) { uint32_t d = x - P; return d < x ? d : x; }   // p -> 0
     __host__ __device__ static inline elem sqr(elem a) { return mul(a, a); }
     __host__ __device__ static inline elem pow_u64(elem a, uint64_t e) {
         elem r = 1;

@@ -198,6 +198,8 @@ struct Secp256k1 {
     }
     __host__ __device__ static inline elem tmul(const telem& T, const elem& x) { return mul2(T.t, T.u, x); }
     __host__ __device__ static inline elem tmul_add(const telem& T, const elem& x, const elem& c) { return mul2_add(T.t, T.u, x, c); }
+    // the butterfly kernels' values are always canonical for this field (M31 keeps a lazy range, see field_m31.h)
+    __host__ __device__ static inline const elem& canon(const elem& x) { return x; }
     __host__ __device__ static inline elem sqr(const elem& a) { return mul(a, a); }
 
     __host__ __device__ static inline elem pow_u64(const elem& a, uint64_t e) {

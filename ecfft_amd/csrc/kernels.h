@@ -19,6 +19,9 @@ namespace ecfft {
 
 constexpr int kBlock = 256;
 
+// Value ranges: inside a kernel (registers, LDS) field elements may be in the field's LAZY range (F::tmul / F::tmul_add /
+// F::sub keep them there: [0, p] for M31, canonical for secp256k1); every store to HBM goes through F::canon(), so all
+// arrays between launches, and everything the caller sees, are canonical residues.
 // ---------------------------------------------------------------------------------------------
 // streaming butterfly stages (one launch per stage).  On the hot path only the cyclic shards of a
 // multi-GPU split EXTEND use them (log2 P stages with strided tables); everything else is fused below.
@@ -39,8 +42,8 @@ __global__ __launch_bounds__(kBlock) void k_decompose_stage(typename F::elem* __
     typename F::elem a = buf[idx], b = buf[idx + h];
     typename F::elem q1 = F::tmul(dinv[i], F::sub(b, a));
     typename F::elem q0 = F::tmul_add(np0[i], q1, a);
-    buf[idx] = q0;
-    buf[idx + h] = q1;
+    buf[idx] = F::canon(q0);
+    buf[idx + h] = F::canon(q1);
 }
 
 template <class F>
@@ -55,8 +58,8 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
     size_t idx = ((g >> log_h) << (log_h + 1)) + i;
     i = i * tstride + toff;
     typename F::elem a = buf[idx], b = buf[idx + h];
-    buf[idx] = F::tmul_add(p0[i], b, a);
-    buf[idx + h] = F::tmul_add(p1[i], b, a);
+    buf[idx] = F::canon(F::tmul_add(p0[i], b, a));
+    buf[idx + h] = F::canon(F::tmul_add(p1[i], b, a));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -92,17 +95,17 @@ __device__ __forceinline__ void io_store(const IoDesc<F>& io, size_t pos, uint32
     using E = typename F::elem;
     const size_t emask = ((size_t)1 << log_e) - 1, i = pos & emask;
     switch (io.st_mode) {
-        case ST_PLAIN: io.dst[pos] = x; break;
-        case ST_SCALE: io.dst[pos] = F::tmul(io.st_a[i], x); break;
+        case ST_PLAIN: io.dst[pos] = F::canon(x); break;
+        case ST_SCALE: io.dst[pos] = F::canon(F::tmul(io.st_a[i], x)); break;
         case ST_AXPBY: {
-            E r = F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+            E r = F::canon(F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off])));
             io.dst[pos] = r;
             if (io.aux_out) io.aux_out[pos] = r;
             break;
         }
         default: {  // ST_EXIT_SPLIT
-            E u0 = F::tmul(io.st_a[i], x);
-            E v0 = F::tmul(io.st_b[i], F::sub(io.aux[2 * pos], u0));
+            E u0 = F::canon(F::tmul(io.st_a[i], x));
+            E v0 = F::canon(F::tmul(io.st_b[i], F::sub(io.aux[2 * pos], u0)));
             size_t base = (pos >> log_e) << (log_e + 1);
             io.dst[base + i] = u0;
             io.dst[base + ((size_t)1 << log_e) + i] = v0;
@@ -119,7 +122,7 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
     E r = x;
     if (io.st_mode == ST_SCALE) r = F::tmul(io.st_a[i], x);
     else if (io.st_mode == ST_AXPBY) {
-        r = F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off]));
+        r = F::canon(F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off])));
         if (io.aux_out) io.aux_out[pos] = r;
     }
     if (io.ld_mode == LD_SCALE) r = F::tmul(io.ld_tbl[i], r);
@@ -169,8 +172,8 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
                 const uint32_t t0[4] = {v0.x, v0.y, v0.z, v0.w}, t1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (DEC) { E q1 = F::mul(t1[c], F::sub(xb[c], xa[c])); xa[c] = F::mul_add(t0[c], q1, xa[c]); xb[c] = q1; }
-                    else { E o0 = F::mul_add(t0[c], xb[c], xa[c]), o1 = F::mul_add(t1[c], xb[c], xa[c]); xa[c] = o0; xb[c] = o1; }
+                    if (DEC) { E q1 = F::tmul(t1[c], F::sub(xb[c], xa[c])); xa[c] = F::tmul_add(t0[c], q1, xa[c]); xb[c] = q1; }
+                    else { E o0 = F::tmul_add(t0[c], xb[c], xa[c]), o1 = F::tmul_add(t1[c], xb[c], xa[c]); xa[c] = o0; xb[c] = o1; }
                 }
                 *reinterpret_cast<uint4*>(a_ + idx) = make_uint4(xa[0], xa[1], xa[2], xa[3]);
                 *reinterpret_cast<uint4*>(a_ + idx + h) = make_uint4(xb[0], xb[1], xb[2], xb[3]);
@@ -262,8 +265,8 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
                 const uint32_t t0[4] = {v0.x, v0.y, v0.z, v0.w}, t1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (DEC) { E q1 = F::mul(t1[c], F::sub(xb[c], xa[c])); xa[c] = F::mul_add(t0[c], q1, xa[c]); xb[c] = q1; }
-                    else { E o0 = F::mul_add(t0[c], xb[c], xa[c]), o1 = F::mul_add(t1[c], xb[c], xa[c]); xa[c] = o0; xb[c] = o1; }
+                    if (DEC) { E q1 = F::tmul(t1[c], F::sub(xb[c], xa[c])); xa[c] = F::tmul_add(t0[c], q1, xa[c]); xb[c] = q1; }
+                    else { E o0 = F::tmul_add(t0[c], xb[c], xa[c]), o1 = F::tmul_add(t1[c], xb[c], xa[c]); xa[c] = o0; xb[c] = o1; }
                 }
                 *reinterpret_cast<uint4*>(tile + lo) = make_uint4(xa[0], xa[1], xa[2], xa[3]);
                 *reinterpret_cast<uint4*>(tile + hi) = make_uint4(xb[0], xb[1], xb[2], xb[3]);
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
     }
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        io.dst[B + ((size_t)r << log_hs) + cc] = tile[r * col_row_stride<E>(C) + cc];
+        io.dst[B + ((size_t)r << log_hs) + cc] = F::canon(tile[r * col_row_stride<E>(C) + cc]);
     }
 }
 
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
         }
         __syncthreads();
     }
-    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = cur[j];
+    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
 }
 
 // EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
         }
         __syncthreads();
     }
-    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = cur[j];
+    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_by_table(typename F::elem* dst
                                                             size_t tbl_mask, size_t n, uint32_t tstride, uint32_t toff) {
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
-    dst[g] = F::tmul(tbl[(g & tbl_mask) * tstride + toff], src[g]);
+    dst[g] = F::canon(F::tmul(tbl[(g & tbl_mask) * tstride + toff], src[g]));
 }
 
 // dst[b*m + 2i]   = u0[i] + xe[i]*v0[i]                (src block  = [u0 | v0])
@@ -565,8 +568,8 @@ __global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __re
     typename F::elem U1 = work[base + i], V1 = work[base + e + i];
     typename F::elem even = F::tmul_add(xe[i], v0, u0);
     typename F::elem odd = F::tmul_add(w1x[i], V1, F::tmul(w1[i], U1));
-    dst[base + 2 * i] = even;
-    dst[base + 2 * i + 1] = odd;
+    dst[base + 2 * i] = F::canon(even);
+    dst[base + 2 * i + 1] = F::canon(odd);
 }
 
 // ---------------------------------------------------------------------------------------------

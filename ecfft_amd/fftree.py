@@ -127,7 +127,7 @@ class Field:
         return FFTree(self, h, device)
 
     def selftest(self, op, a, b, c=None, device=0):
-        """device field arithmetic on raw residues (test hook): op 0 a*b+c, 1 a*b, 2 a-b, 3 a+b"""
+        """device field arithmetic on raw residues (test hook): op 0 a*b+c, 1 a*b, 2 a-b, 3 a+b, 4/5 the kernels' table multiply a*b+c / a*b"""
         a = np.ascontiguousarray(a, self.dtype); b = np.ascontiguousarray(b, self.dtype)
         cc = None if c is None else np.ascontiguousarray(c, self.dtype)
         out = np.empty_like(a)

@@ -147,7 +147,8 @@ int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n);
 int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
 
 /* Test hook: the DEVICE field arithmetic on raw residues (plain integers < p, no Montgomery interpretation), host buffers.
- * op 0: out = a*b + c mod p   1: a*b   2: a - b   3: a + b.  Lets the tests drive the hand-written gfx950 multiply with
+ * op 0: out = a*b + c mod p   1: a*b   2: a - b   3: a + b   4 / 5: a*b + c / a*b with a taken as a TABLE constant, i.e. the
+ * multiply of the butterfly kernels, result in the kernels' internal (lazy) range, not canonicalised.  Lets the tests drive the hand-written gfx950 multiply with
  * directed operands (results next to p and 2^256, carry-out of the second fold) that random data never reaches. */
 int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device);
 

@@ -68,6 +68,16 @@ def test_secp_mul_add_directed():
     assert got == [(x * y) % P256 for x, y, z in T]
 
 
+def test_secp_table_multiply_directed():
+    """the two-table (t, t*2^128) multiply the butterfly kernels use: canonical results on the same directed operands"""
+    import ecfft_amd
+    F = ecfft_amd.secp256k1
+    T = directed_triples()
+    a, b, c = pack256([t[0] for t in T]), pack256([t[1] for t in T]), pack256([t[2] for t in T])
+    assert unpack256(F.selftest(4, a, b, c)) == [(x * y + z) % P256 for x, y, z in T]
+    assert unpack256(F.selftest(5, a, b)) == [(x * y) % P256 for x, y, z in T]
+
+
 def test_secp_add_sub_directed():
     import ecfft_amd
     F = ecfft_amd.secp256k1
@@ -89,3 +99,25 @@ def test_m31_directed():
     assert [int(v) for v in F.selftest(1, a, b)] == [(x * y) % P31 for x, y, z in T]
     assert [int(v) for v in F.selftest(2, a, b)] == [(x - y) % P31 for x, y, z in T]
     assert [int(v) for v in F.selftest(3, a, b)] == [(x + y) % P31 for x, y, z in T]
+
+
+def test_m31_lazy_table_multiply():
+    """M31's kernel-internal multiply keeps values in [0, p] (p = second representative of 0): table constant canonical,
+    data and addend anywhere in [0, p], including the extreme (p-1)*p + p = p^2 that the range proof rests on"""
+    import ecfft_amd
+    F = ecfft_amd.m31
+    rnd = random.Random(5)
+    edge_t = [0, 1, 2, P31 - 1, P31 - 2, 2**30, 2**30 + 1, 65535, 65536]
+    edge_x = [0, 1, 2, P31, P31 - 1, P31 - 2, 2**30, 2**30 - 1, 2**16]
+    T = [(a, b, c) for a in edge_t for b in edge_x for c in edge_x]
+    T += [(rnd.randrange(P31), rnd.randrange(P31 + 1), rnd.randrange(P31 + 1)) for _ in range(50000)]
+    a = np.array([t[0] for t in T], dtype=np.uint32); b = np.array([t[1] for t in T], dtype=np.uint32); c = np.array([t[2] for t in T], dtype=np.uint32)
+    for op in (4, 5):
+        got = [int(v) for v in F.selftest(op, a, b, c)]
+        assert max(got) <= P31
+        want = [(x * y + (z if op == 4 else 0)) % P31 for x, y, z in T]
+        assert [g % P31 for g in got] == want
+    # sub on the lazy range stays in the lazy range
+    aa = np.array([0, P31, 0, P31, 5, P31 - 1], dtype=np.uint32); bb = np.array([P31, 0, 0, P31, P31, P31], dtype=np.uint32)
+    d = [int(v) for v in F.selftest(2, aa, bb)]
+    assert max(d) <= P31 and [v % P31 for v in d] == [(int(x) - int(y)) % P31 for x, y in zip(aa, bb)]
