@@ -33,6 +33,13 @@ def w_mul(n):
     return 2 * n * L * (L - 1) + n * L, 4 * n * L * (L - 1) + 4.5 * n * L
 
 
+def executed_mul(n):
+    """multiplies the HIP path really executes (normalised butterflies, merged innermost stage):
+    ENTER (L^2 + L/2 + 1) n, EXIT (2 L^2 + 2) n"""
+    L = n.bit_length() - 1
+    return (L * L + 0.5 * L + 1) * n, (2 * L * L + 2) * n
+
+
 def b_alg(n, s):
     L = n.bit_length() - 1
     enter = s * (2 * n * L * (L - 1) + 8 * (n - 1 - L) + 3 * n * L + 2 * (n - 1))
@@ -231,6 +238,17 @@ def main():
                         "kernels": [{k: c[k] for k in ("name", "launches", "ms", "alg_bytes")} for c in classes if c["launches"]]}
             be, bx = b_alg(n, F.elem_bytes)
             roofline["alg_bytes_check"] = {"profiler_sum_per_step": tot_alg / args.steps, "closed_form": be + bx}
+            # the binding resource is the integer VALU: price the executed multiplies against the bare multiply chain
+            # measured now on this chip at the kernels' occupancy (4 waves/SIMD)
+            try:
+                ceil4 = F.mul_ceiling(4, local_rank)
+                xe_, xx_ = executed_mul(n)
+                roofline["valu"] = {"bound": "integer VALU (modular multiply)", "executed_mul_per_step": xe_ + xx_,
+                                    "achieved": (xe_ + xx_) / (elapsed / args.steps), "peak": ceil4, "unit": "mul/s",
+                                    "frac": (xe_ + xx_) / (elapsed / args.steps) / ceil4,
+                                    "note": "peak = ecfft_mul_ceiling: the kernels' table multiply as a bare dependent chain, 4 waves/SIMD, whole chip"}
+            except Exception as ex:  # pragma: no cover
+                roofline["valu"] = {"error": str(ex)}
 
     # ---- extra: batched throughput (B independent polynomials share every launch; not the headline value) -----
     batched = None

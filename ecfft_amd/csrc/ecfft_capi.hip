@@ -305,6 +305,53 @@ int run_selftest(int op, const void* a, const void* b, const void* c, void* out,
     return ok ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
+// dependent chain x <- T*x + c per lane: the table multiply of the butterfly kernels with nothing else around it
+template <class F>
+__global__ __launch_bounds__(256) void k_mul_chain(const typename F::elem* t, typename F::elem* x, int iters) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    typename F::telem tv = F::to_table(t[g]);
+    typename F::elem xv = x[g], cv = t[g];
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) xv = F::tmul_add(tv, xv, cv);
+    x[g] = F::canon(xv);
+}
+
+template <class F>
+int run_mul_ceiling(int device, int waves_per_simd, double* mul_per_s) {
+    using E = typename F::elem;
+    if (!mul_per_s || waves_per_simd < 1 || waves_per_simd > 8) return ECFFT_ERR_BAD_ARG;
+    hipDeviceProp_t p;
+    if (!have_device(device) || hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&p, device) != hipSuccess) return ECFFT_ERR_HIP;
+    const int blocks = p.multiProcessorCount * waves_per_simd, iters = sizeof(E) == 32 ? 512 : 8192;   // one 256-thread block = one wave per SIMD
+    const size_t n = (size_t)blocks * 256;
+    std::vector<E> h(n);
+    uint64_t sd = 88172645463325252ull;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char* b = reinterpret_cast<unsigned char*>(&h[i]);
+        for (size_t k = 0; k < sizeof(E); ++k) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; b[k] = (unsigned char)(sd >> 24); }
+        b[sizeof(E) - 1] &= 0x3F;                                                    // < p for both fields
+    }
+    E *dt = nullptr, *dx = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc(&dt, n * sizeof(E)) == hipSuccess && hipMalloc(&dx, n * sizeof(E)) == hipSuccess &&
+              hipMemcpy(dt, h.data(), n * sizeof(E), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, h.data(), n * sizeof(E), hipMemcpyHostToDevice) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    float best = 1e30f;
+    for (int r = 0; ok && r < 4; ++r) {
+        ok = hipEventRecord(e0, nullptr) == hipSuccess;
+        hipLaunchKernelGGL(k_mul_chain<F>, dim3(blocks), dim3(256), 0, nullptr, (const E*)dt, dx, iters);
+        ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        float ms = 0; ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (ok && r > 0 && ms < best) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dt); (void)hipFree(dx);
+    if (!ok) return ECFFT_ERR_HIP;
+    *mul_per_s = (double)n * iters / (best * 1e-3);
+    return ECFFT_OK;
+}
+
 extern "C" {
 
 size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
@@ -534,6 +581,12 @@ int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n) {
 int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
     if (field == ECFFT_FIELD_SECP256K1) return run_selftest<Secp256k1>(op, a, b, c, out, n, device);
     if (field == ECFFT_FIELD_M31) return run_selftest<M31>(op, a, b, c, out, n, device);
+    return ECFFT_ERR_BAD_ARG;
+}
+
+int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
+    if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
+    if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);
     return ECFFT_ERR_BAD_ARG;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_selftest_field", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
 
 
 class Moiety(enum.IntEnum):
@@ -74,6 +74,7 @@ def lib():
         L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
         L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
         L.ecfft_selftest_field.restype, L.ecfft_selftest_field.argtypes = ci, [ci, ci, vp, vp, vp, vp, sz, ci]
+        L.ecfft_mul_ceiling.restype, L.ecfft_mul_ceiling.argtypes = ci, [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ecfft_elems_to_standard.restype, L.ecfft_elems_to_standard.argtypes = ci, [ci, vp, vp, sz]
         L.ecfft_elems_from_standard.restype, L.ecfft_elems_from_standard.argtypes = ci, [ci, vp, vp, sz]
         L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
@@ -133,6 +134,12 @@ class Field:
         out = np.empty_like(a)
         _check(lib().ecfft_selftest_field(self.id, op, a.ctypes.data, b.ctypes.data, None if cc is None else cc.ctypes.data, out.ctypes.data, a.shape[0], device))
         return out
+
+    def mul_ceiling(self, waves_per_simd=4, device=0):
+        """field multiplies per second of the kernels' table multiply as a bare dependent chain on the whole chip"""
+        r = ctypes.c_double()
+        _check(lib().ecfft_mul_ceiling(self.id, device, waves_per_simd, ctypes.byref(r)))
+        return r.value
 
     def to_standard(self, a):
         """in-memory elements -> standard-form little-endian integers (same array shape)"""

@@ -152,6 +152,11 @@ int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
  * directed operands (results next to p and 2^256, carry-out of the second fold) that random data never reaches. */
 int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device);
 
+/* Measurement hook: field multiplies per second of the butterfly kernels' table multiply run as a bare dependent chain
+ * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot
+ * path against beside the HBM roofline. */
+int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s);
+
 /* library / device identification for logs: writes a NUL-terminated string */
 int ecfft_device_info(int device, char* buf, size_t cap);
 
