@@ -65,3 +65,18 @@ def test_host_point_sets_large(prod, oracle_mod):
     ot = F.build_fftree(1 << 16)
     f, _, _ = prod.m31.build_points(1 << 16)
     assert np.array_equal(f[1:], ot.table(oracle_mod.T_F)[1:])
+
+
+def test_generated_multiply_is_in_sync_with_its_generator(tmp_path):
+    """ecfft_amd/csrc/secp256k1_mul_gfx950.inc is generated code: the committed file must be what tools/gen_mulmod_asm.py
+    writes today (default knobs)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "mul.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ECFFT_MUL_")}
+    env["ECFFT_MUL_OUT"] = str(out)
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_mulmod_asm.py")], check=True, env=env, capture_output=True)
+    with open(os.path.join(root, "ecfft_amd", "csrc", "secp256k1_mul_gfx950.inc")) as f:
+        assert f.read() == out.read_text()

@@ -14,7 +14,7 @@ Scheme (DESIGN.md "Field arithmetic on the CDNA4 VALU"):
 """
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ecfft_amd", "csrc", "secp256k1_mul_gfx950.inc")
+OUT = os.environ.get("ECFFT_MUL_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ecfft_amd", "csrc", "secp256k1_mul_gfx950.inc")
 
 
 def pair_name(k):
