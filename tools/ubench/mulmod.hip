@@ -72,7 +72,7 @@ int main() {
         printf("two-table variant vs one-table (all %d lanes): %s (%d)\n", n, bad2 ? "MISMATCH" : "ok", bad2);
         bad += bad2;
         hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
-        for (int wpb = 4; wpb <= 8; wpb += 4) {
+        for (int wpb = 1; wpb <= 8; wpb *= 2) {
             int grid = 256 * wpb; float best = 1e30f;
             for (int r = 0; r < 5; ++r) {
                 (void)hipEventRecord(f0); k_chain2<<<grid, 256>>>(dt, du, dc, dx); (void)hipEventRecord(f1); (void)hipEventSynchronize(f1);
