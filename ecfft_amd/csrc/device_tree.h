@@ -17,6 +17,7 @@
 #include <vector>
 #include <mutex>
 #include <cstdio>
+#include <new>
 #include "kernels.h"
 #include "host_curve.h"
 
@@ -26,6 +27,12 @@ namespace ecfft {
     do { hipError_t e_ = (x); if (e_ != hipSuccess) {                                      \
              fprintf(stderr, "ecfft: HIP error '%s' at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
              return false; } } while (0)
+
+// Allocation failures inside the chain (table arena, temporaries) unwind to the C-ABI entry point, which maps them to
+// ECFFT_ERR_HIP — a shared library must never abort() its host process.
+struct DeviceAllocError : std::bad_alloc {
+    const char* what() const noexcept override { return "ecfft: device allocation failed"; }
+};
 
 static inline unsigned ilog2(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
 static inline unsigned nblocks(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -139,8 +146,7 @@ public:
         }
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
         if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
-        for (void* p : temps_) (void)hipFree(p);
-        temps_.clear();
+        temps_free();
         ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
         ECFFT_HIP_TRY(hipMemcpy(d_trees_, trees_.data(), (L_ + 1) * sizeof(Tree), hipMemcpyHostToDevice));
         return true;
@@ -179,9 +185,13 @@ public:
     // core's first column pass run as ONE launch (k_stages_col_mid) and the function returns true; the next core is then
     // called with skip_first_col = true.
     struct NextLoad { int ld_mode; const TE* ld_tbl; double extra_first; };
+    // ENTER fusion: `ef` != nullptr says that this core is the EXTEND of an ENTER level (total = whole [u0 | v0] blocks, target
+    // S1) and that its LAST pass must also do the level's combine (src/fftree.rs:155-159) and write the level's output to
+    // ef->dst — k_stages_col_enter when the core ends in a column pass, the row kernel's ST_ENTER store operator otherwise.
+    struct EnterFuse { const E* src; E* dst; double extra; };
     bool extend_core(unsigned log_m, IoDesc<F> io, E* buf, size_t total, int srcpar, hipStream_t s,
                      double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0,
-                     const NextLoad* next_ld = nullptr, bool skip_first_col = false) const {
+                     const NextLoad* next_ld = nullptr, bool skip_first_col = false, const EnterFuse* ef = nullptr) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
         const Tree& T = trees_[log_m];
         size_t e = T.e; unsigned le = ilog2(e);
@@ -190,6 +200,7 @@ public:
         unsigned log_tile = tz < kLogTileMax ? tz : kLogTileMax;
         unsigned k_first = le > log_tile ? le - log_tile : 0;                 // first stage with 2h <= tile
         if (k_first < k_begin) k_first = k_begin;
+        if (ef && k_first == 0 && le + 1 > log_tile) log_tile = le + 1;       // ST_ENTER wants whole [U | V] blocks in the tile (64 KiB at e = tile)
         // pass list: (kind, ka, kb)
         struct Pass { int kind; unsigned ka, kb; };                           // kind 0 col-decompose, 1 row, 2 col-recombine
         Pass passes[2 * 8 + 1]; int np = 0;
@@ -222,6 +233,18 @@ public:
                              d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
                 return true;
             }
+            if (last && ef && passes[pi].kind == 2) {
+                // last recombine group (stages kb..0) + the ENTER level's combine, two vectors per workgroup
+                const Pass& P = passes[pi];
+                unsigned log_ct = le < kLogColTileMax ? le : kLogColTileMax;
+                unsigned R = P.kb + 1, log_c = log_ct - R;
+                double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
+                double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + ef->extra;
+                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_enter<F>, dim3((unsigned)(total >> (log_ct + 1))), dim3(kBlockLds),
+                             2 * sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R), s,
+                             (const E*)buf, ef->src, ef->dst, T.p0[tgt], T.p1[tgt], T.xe, T.w[1], T.w1x, le, P.kb, log_c);
+                return false;
+            }
             // load side
             if (first) { d = io; } else { d = IoDesc<F>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
             // store side
@@ -229,11 +252,18 @@ public:
             else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
             double extra = (first ? extra_first : 0.0) + (last ? extra_last : 0.0);
             const Pass& P = passes[pi];
+            if (last && ef) {   // row pass is the last one: pair store operator
+                d.dst = ef->dst; d.st_mode = ST_ENTER; d.st_a = T.xe; d.st_b = T.w1x; d.st_c = T.w[1]; d.aux = ef->src; d.aux_stride = 1; d.aux_off = 0; d.aux_out = nullptr;
+                extra += ef->extra;
+            }
             if (P.kind == 1) {
                 unsigned nst = le - k_first;
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
-                if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
+                if (log_tile == kLogTileMax + 1 && (sizeof(E) == 4 || ECFFT_CT_ALL))
+                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
+                else if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
                 else
@@ -265,7 +295,7 @@ public:
 
     // FFTree::extend (src/fftree.rs:123-126) on `count` vectors of length e: uses T_{2e}; `target`
     // names the TARGET moiety.  in/out device pointers (may alias).
-    void extend(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) const {
+    bool extend(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) const {
         unsigned log_m = ilog2(e) + 1;
         const Tree& T = trees_[log_m];
         size_t total = e * count; int src = 1 - target;
@@ -273,6 +303,7 @@ public:
         io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[src];
         io.st_mode = ST_SCALE; io.st_a = T.w[target];
         extend_core(log_m, io, out, total, src, s);
+        return hipGetLastError() == hipSuccess;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -364,9 +395,10 @@ public:
             const Tree& T = trees_[l];
             size_t e = T.e;
             E* dst = (l == l_end && out != in) ? out : (src == bufA ? bufB : bufA);
-            { IoDesc<F> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0]; extend_core(l, io, work, nt, 0, s); }
-            ECFFT_LAUNCH(KC_POINTWISE, sizeof(E) * (3.0 * nt + 2.0 * e * tblw_), k_enter_combine<F>, dim3(nblocks(nt / 2)), dim3(kBlock), 0, s,
-                         dst, src, (const E*)work, T.xe, T.w[1], T.w1x, ilog2(e), nt / 2);
+            // EXTEND of every [u0 | v0] half onto S1 with the combine (:155-159) folded into its last pass
+            IoDesc<F> io = io_plain(src, work); io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[0];
+            EnterFuse ef{src, dst, sizeof(E) * (3.0 * nt + 2.0 * e * tblw_)};
+            extend_core(l, io, work, nt, 0, s, 0.0, 0.0, 0, nullptr, false, &ef);
             src = dst;
         }
         if (src != out) (void)hipMemcpyAsync(out, src, nt * sizeof(E), hipMemcpyDeviceToDevice, s);
@@ -497,37 +529,36 @@ public:
         b_vanish(ilog2(nd) + 1, dom, out, s, true);
         return finish_api(s);
     }
-    // degree (src/fftree.rs:195-198), data-dependent recursion driven from the host: one flag read per level
+    // degree (src/fftree.rs:169-198).  The reference's recursion is data dependent (g1 == e1 ? recurse on e0 : recurse on t0);
+    // here every level computes BOTH candidates and a device-side flag selects between them, so the whole descent is
+    // enqueued without a single host round trip (was: one stream synchronise per level) and the degree is read back once.
     bool api_degree(const E* evals, size_t n, hipStream_t s, size_t* degree) {
-        size_t deg = 0;
+        unsigned long long hdeg = 0;
         if (n > 1) {
             E* cur = temp(n); E* e0 = temp(n / 2); E* e1 = temp(n / 2); E* g1 = temp(n / 2);
-            int* flag = nullptr;
-            if (hipMalloc(&flag, sizeof(int)) != hipSuccess) return false;
-            temps_.push_back(flag);
+            unsigned long long* acc = reinterpret_cast<unsigned long long*>(temp((2 * sizeof(unsigned long long) + sizeof(E) - 1) / sizeof(E)));   // {degree, flag}
+            (void)hipMemsetAsync(acc, 0, 2 * sizeof(unsigned long long), s);
             (void)hipMemcpyAsync(cur, evals, n * sizeof(E), hipMemcpyDeviceToDevice, s);
             for (size_t m = n; m >= 2; m >>= 1) {
                 unsigned l = ilog2(m); size_t e = m / 2;
                 const Tree& T = trees_[l];
                 foreach_n(s, e, [=] __device__(size_t i) { e0[i] = cur[2 * i]; e1[i] = cur[2 * i + 1]; });
                 b_extend(l, e0, g1, 1, 1, s);                               // :180
-                (void)hipMemsetAsync(flag, 0, sizeof(int), s);
-                foreach_n(s, e, [=] __device__(size_t i) { if (!F::eq(g1[i], e1[i])) atomicOr(flag, 1); });
-                int hflag = 0;
-                if (hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
-                if (hipStreamSynchronize(s) != hipSuccess) return false;
-                if (!hflag) {                                               // degree < m/2 (:181-183)
-                    (void)hipMemcpyAsync(cur, e0, e * sizeof(E), hipMemcpyDeviceToDevice, s);
-                } else {                                                    // :187-191
-                    const E* zi = T.z0_inv_s1;
-                    foreach_n(s, e, [=] __device__(size_t i) { e1[i] = F::mul(F::sub(e1[i], g1[i]), zi[i]); });
-                    b_extend(l, e1, cur, 1, 0, s);
-                    deg += e;
-                }
+                const E* zi = T.z0_inv_s1;
+                foreach_n(s, e, [=] __device__(size_t i) {                  // :181 (flag) and :187-189 (t1, kept in e1)
+                    E d = F::sub(e1[i], g1[i]);
+                    if (!F::is_zero(d)) atomicOr(acc + 1, 1ull);
+                    e1[i] = F::mul(d, zi[i]);
+                });
+                b_extend(l, e1, g1, 1, 0, s);                               // t0 (:190)
+                foreach_n(s, e, [=] __device__(size_t i) { cur[i] = acc[1] ? g1[i] : e0[i]; });   // :182 / :191
+                foreach_n(s, 1, [=] __device__(size_t) { if (acc[1]) acc[0] += (unsigned long long)e; acc[1] = 0; });
             }
+            if (hipMemcpyAsync(&hdeg, acc, sizeof(hdeg), hipMemcpyDeviceToHost, s) != hipSuccess) { temps_done(); return false; }
         }
-        *degree = deg;
-        return finish_api(s);
+        bool ok = finish_api(s);
+        *degree = (size_t)hdeg;
+        return ok;
     }
 
     // The reference's own (un-normalised) matrices of T_m, rebuilt on demand for export (src/fftree.rs:341-363):
@@ -599,7 +630,7 @@ private:
     // ---- memory ----
     E* take(size_t n) {
         size_t a = (n + 7) & ~(size_t)7;
-        if (arena_used_ + a > arena_cap_) { fprintf(stderr, "ecfft: internal error: table arena overflow\n"); abort(); }   // sized exactly in build(); unreachable
+        if (arena_used_ + a > arena_cap_) { fprintf(stderr, "ecfft: internal error: table arena overflow\n"); throw DeviceAllocError(); }   // sized exactly in build(); unreachable
         E* p = arena_ + arena_used_; arena_used_ += a; return p;
     }
     static constexpr size_t kTeElems = sizeof(TE) / sizeof(E);
@@ -615,13 +646,22 @@ private:
     E* temp(size_t n) {
         size_t a = (n + 7) & ~(size_t)7;
         if (slab_ && slab_used_ + a <= slab_cap_) { E* q = slab_ + slab_used_; slab_used_ += a; return q; }
+        // pooled individual allocations: finish_api() / build_tree() hand them back to the pool instead of freeing them,
+        // so repeated algorithm calls (ecfft_redc, ecfft_degree, ...) do not hipMalloc / hipFree every time
+        size_t bytes = (a ? a : 8) * sizeof(E);
+        int best = -1;
+        for (size_t i = 0; i < pool_.size(); ++i)
+            if (!pool_[i].busy && pool_[i].bytes >= bytes && (best < 0 || pool_[i].bytes < pool_[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) { pool_[(size_t)best].busy = true; return (E*)pool_[(size_t)best].p; }
         void* p = nullptr;
-        if (hipMalloc(&p, (n ? n : 1) * sizeof(E)) != hipSuccess) { fprintf(stderr, "ecfft: temp alloc failed\n"); abort(); }
-        temps_.push_back(p); return (E*)p;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "ecfft: temporary allocation of %zu bytes failed\n", bytes); throw DeviceAllocError(); }
+        pool_.push_back({p, bytes, true});
+        return (E*)p;
     }
+    void temps_done() { for (auto& b : pool_) b.busy = false; }
+    void temps_free() { for (auto& b : pool_) (void)hipFree(b.p); pool_.clear(); }
     void release() {
-        for (void* p : temps_) (void)hipFree(p);
-        temps_.clear();
+        temps_free();
         if (arena_) (void)hipFree(arena_);
         if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
         if (scratch_) (void)hipFree(scratch_);
@@ -642,8 +682,7 @@ private:
     }
     bool finish_api(hipStream_t s) {
         bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-        for (void* p : temps_) (void)hipFree(p);
-        temps_.clear();
+        temps_done();
         return ok;
     }
     // user table a (crate representation, 2e entries) -> plain even entries (to be inverted) and plain odd entries
@@ -653,7 +692,8 @@ private:
     }
 
     // ---- construction-time device primitives (plain data) ----
-    // out[i] = 1/in[i]; chunks of 8 share one Fermat inversion (Montgomery's trick)
+    // out[i] = 1/in[i]; chunks of 8 share one Fermat inversion (Montgomery's trick).  Zero entries stay zero and do not
+    // disturb their neighbours, like ark_ff::batch_inversion (used at src/fftree.rs:235, 331-333, 409-414).
     void batch_inv(const E* in, E* out, size_t n, hipStream_t s) {
         constexpr size_t CH = 8;
         size_t nth = (n + CH - 1) / CH;
@@ -661,9 +701,12 @@ private:
             size_t b = t * CH, cnt = (b + CH <= n) ? CH : n - b;
             E pre[CH], v[CH];
             E acc = F::one();
-            for (size_t i = 0; i < cnt; ++i) { v[i] = in[b + i]; pre[i] = acc; acc = F::mul(acc, v[i]); }
+            for (size_t i = 0; i < cnt; ++i) { v[i] = in[b + i]; pre[i] = acc; if (!F::is_zero(v[i])) acc = F::mul(acc, v[i]); }
             acc = F::inv(acc);
-            for (size_t i = cnt; i-- > 0;) { out[b + i] = F::mul(acc, pre[i]); acc = F::mul(acc, v[i]); }
+            for (size_t i = cnt; i-- > 0;) {
+                if (F::is_zero(v[i])) { out[b + i] = F::zero(); continue; }
+                out[b + i] = F::mul(acc, pre[i]); acc = F::mul(acc, v[i]);
+            }
         });
     }
     void ew_mul(E* out, const E* a, const E* b, size_t n, hipStream_t s) {
@@ -901,8 +944,7 @@ private:
         if (err != hipSuccess) { fprintf(stderr, "ecfft: kernel launch failed: %s\n", hipGetErrorString(err)); return false; }
         // temporaries are only needed until the stream drains; free them per tree to bound memory
         if (hipStreamSynchronize(s) != hipSuccess) return false;
-        for (void* p : temps_) (void)hipFree(p);
-        temps_.clear();
+        temps_free();
         slab_used_ = 0;
         return true;
     }
@@ -915,7 +957,8 @@ private:
     E* slab_ = nullptr; size_t slab_cap_ = 0, slab_used_ = 0;
     std::vector<Tree> trees_;
     Tree* d_trees_ = nullptr;
-    std::vector<void*> temps_;
+    struct PoolBuf { void* p; size_t bytes; bool busy; };
+    std::vector<PoolBuf> pool_;
     std::mutex mu_;
     mutable Profiler prof_;
     hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;

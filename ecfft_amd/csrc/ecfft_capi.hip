@@ -33,10 +33,22 @@ bool have_device(int device) {
     return true;
 }
 
+// Every entry point that touches the device selects the context's device and puts the caller's current device back on
+// the way out, whatever path it leaves by.
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 template <class F>
 int finish_build(HostTree<F>&& ht, int device, std::unique_ptr<DeviceChain<F>>& slot) {
     slot.reset(new (std::nothrow) DeviceChain<F>());
     if (!slot) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     return slot->build(std::move(ht), device) ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
@@ -64,6 +76,21 @@ bool op_begin(ecfft_ctx* c, hipStream_t s) {
 }
 bool op_end(ecfft_ctx* c, hipStream_t s) { return hipEventRecord(c->last_op, s) == hipSuccess; }
 
+// Orders a call after the previous one on the context (op_begin) and records its completion (op_end) on EVERY exit path
+// after a successful begin — an early error return must not leave `last_op` pointing before work that was enqueued.
+struct OpScope {
+    ecfft_ctx* c; hipStream_t s; bool ok;
+    OpScope(ecfft_ctx* c_, hipStream_t s_) : c(c_), s(s_), ok(op_begin(c_, s_)) {}
+    ~OpScope() { if (ok) (void)op_end(c, s); }
+};
+// no C++ exception (allocation failure inside the chain) crosses the C ABI
+template <class Fn>
+int guarded(Fn fn) {
+    try { return fn(); }
+    catch (const std::bad_alloc&) { return ECFFT_ERR_HIP; }
+    catch (...) { return ECFFT_ERR_HIP; }
+}
+
 enum Op { OP_ENTER, OP_EXIT, OP_EXTEND };
 
 template <class F>
@@ -76,33 +103,32 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
     size_t need_tree = (op == OP_EXTEND) ? len * 2 : len;
     if (need_tree > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;          // "FFTree is too small"
     if (op == OP_EXTEND && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
-    if (op == OP_EXTEND && len * count > 2 * ch.size() && mem == ECFFT_MEM_HOST) { /* staged below; any count allowed */ }
     hipStream_t s = (hipStream_t)stream;
-    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    if (mem != ECFFT_MEM_HOST && mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(c->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     std::lock_guard<std::mutex> guard(ch.lock());
-    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
+    OpScope scope(c, s);
+    if (!scope.ok) return ECFFT_ERR_HIP;
     size_t total = len * count, bytes = total * sizeof(E);
     const E* din = (const E*)in; E* dout = (E*)out;
     if (mem == ECFFT_MEM_HOST) {
         if (!ensure_stage(c, 2 * bytes)) return ECFFT_ERR_HIP;
         din = (const E*)c->stage; dout = (E*)((char*)c->stage + bytes);
         if (hipMemcpyAsync((void*)din, in, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP;
-    } else if (mem != ECFFT_MEM_DEVICE) {
-        return ECFFT_ERR_BAD_ARG;
     }
+    bool ok = true;
     switch (op) {
-        case OP_ENTER: if (!ch.enter(din, dout, len, count, s)) return ECFFT_ERR_HIP; break;
-        case OP_EXIT: if (!ch.exit(din, dout, len, count, s)) return ECFFT_ERR_HIP; break;
-        case OP_EXTEND: ch.extend(din, dout, len, count, moiety, s); break;
+        case OP_ENTER: ok = ch.enter(din, dout, len, count, s); break;
+        case OP_EXIT: ok = ch.exit(din, dout, len, count, s); break;
+        case OP_EXTEND: ok = ch.extend(din, dout, len, count, moiety, s); break;
     }
-    if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
+    if (!ok || hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
     if (mem == ECFFT_MEM_HOST) {
         if (hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
-        if (!op_end(c, s)) return ECFFT_ERR_HIP;
         if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
-        return ECFFT_OK;
     }
-    return op_end(c, s) ? ECFFT_OK : ECFFT_ERR_HIP;
+    return ECFFT_OK;
 }
 
 template <class F>
@@ -166,27 +192,28 @@ int run_shard(ecfft_ctx* c, DeviceChain<F>& ch, void* buf, size_t e, int moiety,
     if (2 * e > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
     if (moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
     if (((size_t)2 << log_p) > e || rank >= (1u << log_p)) return ECFFT_ERR_BAD_ARG;   // need >= 2 elements per rank
-    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    if (mem != ECFFT_MEM_HOST && mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(c->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> guard(ch.lock());
-    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
+    OpScope scope(c, s);
+    if (!scope.ok) return ECFFT_ERR_HIP;
     size_t bytes = (e >> log_p) * sizeof(E);
     E* d = (E*)buf;
     if (mem == ECFFT_MEM_HOST) {
         if (!ensure_stage(c, bytes)) return ECFFT_ERR_HIP;
         d = (E*)c->stage;
         if (hipMemcpyAsync(d, buf, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return ECFFT_ERR_HIP;
-    } else if (mem != ECFFT_MEM_DEVICE) return ECFFT_ERR_BAD_ARG;
+    }
     if (which == 2) ch.extend_local_block(d, e, moiety, log_p, s);
     else ch.extend_top_cyclic(d, e, moiety, log_p, rank, which == 1, s);
     if (hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
     if (mem == ECFFT_MEM_HOST) {
         if (hipMemcpyAsync(buf, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return ECFFT_ERR_HIP;
-        if (!op_end(c, s)) return ECFFT_ERR_HIP;
         if (hipStreamSynchronize(s) != hipSuccess) return ECFFT_ERR_HIP;
-        return ECFFT_OK;
     }
-    return op_end(c, s) ? ECFFT_OK : ECFFT_ERR_HIP;
+    return ECFFT_OK;
 }
 }  // namespace
 
@@ -210,23 +237,28 @@ int run_alg(ecfft_ctx* c, DeviceChain<F>& ch, Alg alg, const void* in0, const vo
     if ((alg == ALG_REDC || alg == ALG_MOD) && len < 2) {   // size-1 tree has no moieties: the reference would index out of bounds
         return ECFFT_ERR_BAD_ARG;
     }
-    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    DeviceGuard dev(c->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> guard(ch.lock());
-    if (!op_begin(c, s)) return ECFFT_ERR_HIP;
+    OpScope scope(c, s);
+    if (!scope.ok) return ECFFT_ERR_HIP;
     size_t n_in = len * count, n_out = (alg == ALG_VANISH ? 2 * len : len) * count;
     const E *d0 = (const E*)in0, *d1 = (const E*)in1, *d2 = (const E*)in2; E* dout = (E*)out;
-    std::vector<void*> owned;
-    auto stage_in = [&](const void* h, size_t n, const E** d) -> bool {
-        if (!h || mem == ECFFT_MEM_DEVICE) return true;
-        void* p = nullptr; if (hipMalloc(&p, n * sizeof(E)) != hipSuccess) return false;
-        owned.push_back(p);
-        if (hipMemcpyAsync(p, h, n * sizeof(E), hipMemcpyHostToDevice, s) != hipSuccess) return false;
-        *d = (const E*)p; return true;
-    };
-    bool ok = stage_in(in0, n_in, &d0) && stage_in(in1, len, &d1) && stage_in(in2, len, &d2);
-    if (ok && mem == ECFFT_MEM_HOST && alg != ALG_DEGREE) {
-        void* p = nullptr; ok = hipMalloc(&p, n_out * sizeof(E)) == hipSuccess; if (ok) { owned.push_back(p); dout = (E*)p; }
+    bool ok = true;
+    if (mem == ECFFT_MEM_HOST) {
+        // host buffers: inputs and the output are staged through ONE context-owned device buffer that grows on demand
+        // and is reused by later calls (no hipMalloc / hipFree per call)
+        size_t need = n_in + (in1 ? len : 0) + (in2 ? len : 0) + (alg != ALG_DEGREE ? n_out : 0);
+        if (!ensure_stage(c, need * sizeof(E))) return ECFFT_ERR_HIP;
+        E* p = (E*)c->stage;
+        auto stage_in = [&](const void* h, size_t n, const E** d) -> bool {
+            if (!h) return true;
+            if (hipMemcpyAsync(p, h, n * sizeof(E), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+            *d = p; p += n; return true;
+        };
+        ok = stage_in(in0, n_in, &d0) && stage_in(in1, len, &d1) && stage_in(in2, len, &d2);
+        if (alg != ALG_DEGREE) dout = p;
     }
     if (ok) {
         switch (alg) {
@@ -239,9 +271,6 @@ int run_alg(ecfft_ctx* c, DeviceChain<F>& ch, Alg alg, const void* in0, const vo
     }
     if (ok && mem == ECFFT_MEM_HOST && alg != ALG_DEGREE)
         ok = hipMemcpyAsync(out, dout, n_out * sizeof(E), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    (void)op_end(c, s);
-    (void)hipStreamSynchronize(s);
-    for (void* p : owned) (void)hipFree(p);
     return ok ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 #define ECFFT_DISPATCH_ALG(...) (ctx->field == ECFFT_FIELD_SECP256K1 ? run_alg(ctx, *ctx->secp, __VA_ARGS__) : run_alg(ctx, *ctx->m31, __VA_ARGS__))
@@ -255,7 +284,8 @@ int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, co
     if (!is_pow2(m)) return ECFFT_ERR_NOT_POW2;
     if (m > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
     if (cnt == 0) return ECFFT_OK;
-    if (hipSetDevice(c->device) != hipSuccess) return ECFFT_ERR_HIP;
+    DeviceGuard dev(c->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> guard(ch.lock());
     const E *dx = (const E*)x, *dy = (const E*)y; E* dout = (E*)out;
@@ -281,7 +311,9 @@ template <class F>
 int run_selftest(int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
     using E = typename F::elem;
     if (!a || !b || !out || ((op == 0 || op == 4) && !c) || op < 0 || op > 5) return ECFFT_ERR_BAD_ARG;
-    if (!have_device(device) || hipSetDevice(device) != hipSuccess) return ECFFT_ERR_HIP;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
     E *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
     size_t bytes = n * sizeof(E);
     bool ok = hipMalloc(&da, bytes) == hipSuccess && hipMalloc(&db, bytes) == hipSuccess && hipMalloc(&dc, bytes) == hipSuccess && hipMalloc(&dout, bytes) == hipSuccess;
@@ -321,7 +353,9 @@ int run_mul_ceiling(int device, int waves_per_simd, double* mul_per_s) {
     using E = typename F::elem;
     if (!mul_per_s || waves_per_simd < 1 || waves_per_simd > 8) return ECFFT_ERR_BAD_ARG;
     hipDeviceProp_t p;
-    if (!have_device(device) || hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&p, device) != hipSuccess) return ECFFT_ERR_HIP;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok || hipGetDeviceProperties(&p, device) != hipSuccess) return ECFFT_ERR_HIP;
     const int blocks = p.multiProcessorCount * waves_per_simd, iters = sizeof(E) == 32 ? 512 : 8192;   // one 256-thread block = one wave per SIMD
     const size_t n = (size_t)blocks * 256;
     std::vector<E> h(n);
@@ -375,13 +409,13 @@ int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
         int r = build_host_tree<Secp256k1>(log_n, ht);
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
-        rc = finish_build(std::move(ht), device, c->secp);
+        rc = guarded([&] { return finish_build(std::move(ht), device, c->secp); });
     } else {
         HostTree<M31> ht;
         int r = build_host_tree<M31>(log_n, ht);
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
-        rc = finish_build(std::move(ht), device, c->m31);
+        rc = guarded([&] { return finish_build(std::move(ht), device, c->m31); });
     }
     if (rc != ECFFT_OK) return rc;
     *out = c.release();
@@ -411,7 +445,7 @@ int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_nu
             if (!Secp256k1::is_zero(ht.maps[k].den[2])) return ECFFT_ERR_BAD_ARG;   // x-map denominators have degree 1
         }
         if (!fill_layers<Secp256k1>(ht)) return ECFFT_ERR_BAD_ARG;
-        rc = finish_build(std::move(ht), device, c->secp);
+        rc = guarded([&] { return finish_build(std::move(ht), device, c->secp); });
     } else {
         HostTree<M31> ht; ht.n = n; ht.f.assign(2 * n, 0); ht.maps.resize(log_n);
         memcpy(ht.f.data() + n, leaves, n * 4);
@@ -420,7 +454,7 @@ int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_nu
             if (ht.maps[k].den[2] != 0) return ECFFT_ERR_BAD_ARG;
         }
         if (!fill_layers<M31>(ht)) return ECFFT_ERR_BAD_ARG;
-        rc = finish_build(std::move(ht), device, c->m31);
+        rc = guarded([&] { return finish_build(std::move(ht), device, c->m31); });
     }
     if (rc != ECFFT_OK) return rc;
     *out = c.release();
@@ -460,7 +494,11 @@ int ecfft_build_points(int field, size_t n, void* f_out, void* map_num3_out, voi
     return ECFFT_ERR_BAD_ARG;
 }
 
-void ecfft_ctx_destroy(ecfft_ctx* ctx) { delete ctx; }
+void ecfft_ctx_destroy(ecfft_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard dev(ctx->device);
+    delete ctx;
+}
 
 size_t ecfft_tree_size(const ecfft_ctx* ctx) {
     if (!ctx) return 0;
@@ -470,80 +508,82 @@ int ecfft_field(const ecfft_ctx* ctx) { return ctx ? ctx->field : -1; }
 
 int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream)
-                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream); });
 }
 int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream)
-                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream); });
 }
 int ecfft_enter_many(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, size_t count, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, count, 0, mem, stream)
-                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, count, 0, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, count, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, count, 0, mem, stream); });
 }
 int ecfft_exit_many(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, size_t count, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, count, 0, mem, stream)
-                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, count, 0, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, count, 0, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, count, 0, mem, stream); });
 }
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXTEND, in, out, e, count, moiety, mem, stream)
-                                               : run_op(ctx, *ctx->m31, OP_EXTEND, in, out, e, count, moiety, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXTEND, in, out, e, count, moiety, mem, stream)
+                                               : run_op(ctx, *ctx->m31, OP_EXTEND, in, out, e, count, moiety, mem, stream); });
 }
 
 int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int recombine, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream)
-                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream)
+                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream); });
 }
 int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, 0, 2, mem, stream)
-                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, 0, 2, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, 0, 2, mem, stream)
+                                               : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, 0, 2, mem, stream); });
 }
 
 int ecfft_mextend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ECFFT_DISPATCH_ALG(ALG_MEXTEND, in, nullptr, nullptr, out, e, count, moiety, mem, stream, nullptr);
+    return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_MEXTEND, in, nullptr, nullptr, out, e, count, moiety, mem, stream, nullptr); });
 }
 int ecfft_redc(ecfft_ctx* ctx, const void* evals, const void* a, void* out, size_t n, int moiety, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ECFFT_DISPATCH_ALG(ALG_REDC, evals, a, nullptr, out, n, 1, moiety, mem, stream, nullptr);
+    return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_REDC, evals, a, nullptr, out, n, 1, moiety, mem, stream, nullptr); });
 }
 int ecfft_modular_reduce(ecfft_ctx* ctx, const void* evals, const void* a, const void* c, void* out, size_t n, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ECFFT_DISPATCH_ALG(ALG_MOD, evals, a, c, out, n, 1, 0, mem, stream, nullptr);
+    return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_MOD, evals, a, c, out, n, 1, 0, mem, stream, nullptr); });
 }
 int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ECFFT_DISPATCH_ALG(ALG_VANISH, domain, nullptr, nullptr, out, nd, 1, 0, mem, stream, nullptr);
+    return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_VANISH, domain, nullptr, nullptr, out, nd, 1, 0, mem, stream, nullptr); });
 }
 int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree);
+    return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree); });
 }
 
 int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
                     size_t t_stride, int mode, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? run_table_fma(ctx, *ctx->secp, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream)
-                                               : run_table_fma(ctx, *ctx->m31, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream);
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_table_fma(ctx, *ctx->secp, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream)
+                                               : run_table_fma(ctx, *ctx->m31, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream); });
 }
 
 int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
-    if (hipSetDevice(ctx->device) != hipSuccess) return ECFFT_ERR_HIP;
-    return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)
-                                               : table_of(*ctx->m31, m, which, host_out, cap, count);
+    DeviceGuard dev(ctx->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)
+                                                                    : table_of(*ctx->m31, m, which, host_out, cap, count); });
 }
 
 int ecfft_profile_enable(ecfft_ctx* ctx, int on) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     Profiler& p = ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->profiler() : ctx->m31->profiler();
-    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    DeviceGuard dev(ctx->device);
+    if (!dev.ok || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
     p.reset(); p.on = on != 0;
     return ECFFT_OK;
 }
@@ -552,7 +592,8 @@ int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t
                        double* alg_bytes_total) {
     if (!ctx || cls < 0 || cls >= KC_COUNT) return ECFFT_ERR_BAD_ARG;
     Profiler& p = ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->profiler() : ctx->m31->profiler();
-    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    DeviceGuard dev(ctx->device);
+    if (!dev.ok || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
     p.collect();
     if (name && cap) snprintf(name, cap, "%s", kKernelClassName[cls]);
     if (launches) *launches = p.launches(cls);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_recombine_stage(typename F::elem* __
 // length e laid end to end), i = pos mod e.
 // ---------------------------------------------------------------------------------------------
 enum { LD_PLAIN = 0, LD_SCALE = 1 };
-enum { ST_PLAIN = 0, ST_SCALE = 1, ST_AXPBY = 2, ST_EXIT_SPLIT = 3 };
+enum { ST_PLAIN = 0, ST_SCALE = 1, ST_AXPBY = 2, ST_EXIT_SPLIT = 3, ST_ENTER = 4 };
 
 template <class F>
 struct IoDesc {
@@ -81,7 +81,10 @@ struct IoDesc {
     //        ST_SCALE  dst[pos] = st_a[i]*x
     //        ST_AXPBY  r = st_a[i]*x + st_b[i]*aux[aux_stride*pos + aux_off]; dst[pos] = r; aux_out[pos] = r (if set)
     //        ST_EXIT_SPLIT  u0 = st_a[i]*x; v0 = st_b[i]*(aux[2*pos] - u0); dst[b*2e + i] = u0; dst[b*2e + e + i] = v0  (b = pos / e)
-    E* dst; int st_mode; const TE* st_a; const TE* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out;
+    //        ST_ENTER  (pair operator, ENTER loop C src/fftree.rs:155-159 in normalised form; x = U1~ at pos = b*2e + i, y = V1~ at
+    //                  pos + e, both still in the tile; aux = the level's input blocks [u0 | v0])
+    //                  dst[b*2e + 2i] = aux[b*2e + i] + st_a[i]*aux[b*2e + e + i];  dst[b*2e + 2i + 1] = st_c[i]*x + st_b[i]*y
+    E* dst; int st_mode; const TE* st_a; const TE* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out; const TE* st_c;
 };
 
 template <class F>
@@ -232,6 +235,19 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
+    }
+    if (io.st_mode == ST_ENTER) {
+        // the tile holds whole [U1~ | V1~] blocks (2e <= T): combine them with the level's input and store interleaved
+        for (uint32_t g = tid; g < npairs; g += kBlockRow) {
+            const uint32_t i = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
+            const size_t bb = base + lb;
+            const E u0 = io.aux[bb + i], v0 = io.aux[bb + e + i];
+            const E ev = F::tmul_add(io.st_a[i], v0, u0);
+            const E od = F::tmul_add(io.st_b[i], tile[lb + (uint32_t)e + i], F::tmul(io.st_c[i], tile[lb + i]));
+            io.dst[bb + 2 * i] = F::canon(ev);
+            io.dst[bb + 2 * i + 1] = F::canon(od);
+        }
+        return;
     }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
@@ -386,6 +402,58 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
 }
 
 // ---------------------------------------------------------------------------------------------
+// The LAST column pass of an ENTER level's EXTEND (recombine stages kb..0) fused with the level's combine step
+// (src/fftree.rs:155-159).  The combine needs U1~[i] and V1~[i] — the same column of two ADJACENT vectors of the batched
+// EXTEND — so one workgroup takes both vectors' column tiles: rows 0..2^R-1 = vector 2b (U), rows 2^R..2^(R+1)-1 = vector
+// 2b+1 (V), R = kb+1, C columns each (64 KiB of LDS).  The stage sweeps never pair across the two halves (row distance
+// <= 2^(R-1)) and both halves read the same table entries.  Store: even = u0 + xe*v0, odd = w1*U1~ + w1x*V1~, interleaved,
+// straight to the level's output — the separate combine launch (3n element moves for 1.5n multiplies, HBM-bound) and the
+// EXTEND's write + re-read of its result are gone.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_enter(const typename F::elem* __restrict__ work, const typename F::elem* __restrict__ src,
+                                                                 typename F::elem* __restrict__ dst,
+                                                                 const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                                                 const typename F::telem* __restrict__ xe, const typename F::telem* __restrict__ w1,
+                                                                 const typename F::telem* __restrict__ w1x,
+                                                                 uint32_t log_e, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
+    E* tile = reinterpret_cast<E*>(ecfft_smem);
+    const uint32_t R = kb + 1, tid = threadIdx.x;
+    const uint32_t C = 1u << log_c, T = C << (R + 1), RS = col_row_stride<E>(C);
+    const size_t e = (size_t)1 << log_e;
+    const uint32_t log_hs = log_e - R;                               // hs = e >> R: row spacing; 2^R rows span one vector
+    const size_t hs = (size_t)1 << log_hs;
+    const uint32_t chunks_log = log_hs - log_c;
+    const size_t b = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+    const size_t c0 = chunk << log_c;
+    const size_t B = (b << (log_e + 1)) + c0;                        // position of (row 0, col 0) of the U vector
+#pragma unroll
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        const uint32_t r = j >> log_c, cc = j & (C - 1);            // r < 2^(R+1): r >> R selects the vector
+        tile[r * RS + cc] = work[B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc];
+    }
+    __syncthreads();
+    const uint32_t npairs = T >> 1;
+    for (uint32_t st = 0; st < R; ++st) {                            // stage k = kb - st, row distance 2^st
+        const size_t h = hs << st;
+        col_stage_sweep<F, false>(tile, p0 + (e - 2 * h), p1 + (e - 2 * h), st, log_c, log_hs, c0, npairs, tid);
+        __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t j = tid; j < (T >> 1); j += kBlockLds) {
+        const uint32_t r = j >> log_c, cc = j & (C - 1);
+        const size_t i = ((size_t)r << log_hs) + c0 + cc, bb = b << (log_e + 1);
+        const E u0 = src[bb + i], v0 = src[bb + e + i];
+        const E ev = F::tmul_add(xe[i], v0, u0);
+        const E od = F::tmul_add(w1x[i], tile[((1u << R) + r) * RS + cc], F::tmul(w1[i], tile[r * RS + cc]));
+        dst[bb + 2 * i] = F::canon(ev);
+        dst[bb + 2 * i + 1] = F::canon(od);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Whole low levels of ENTER / EXIT in LDS.  Level m <= tile only touches data inside one tile-aligned
 // block, so the first log(tile) levels of ENTER (bottom-up) and the last log(tile) levels of EXIT
 // (top-down) run in ONE launch with a single HBM round trip: every pre-scale, butterfly stage and
@@ -536,7 +604,9 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
 }
 
 // ---------------------------------------------------------------------------------------------
-// pointwise kernels of ENTER (src/fftree.rs:143-161) — level m, e = m/2, n/m blocks
+// pointwise scaling by a (strided) table: cyclic shards of a multi-GPU split EXTEND.  (The combine step of ENTER,
+// src/fftree.rs:155-159, has no kernel of its own: it is the store operator of the level's last EXTEND pass — ST_ENTER in
+// k_stages_lds, k_stages_col_enter.)
 // ---------------------------------------------------------------------------------------------
 // work[j] = src[j] * winv0[j mod e]
 template <class F>
@@ -547,29 +617,6 @@ __global__ __launch_bounds__(kBlock) void k_scale_by_table(typename F::elem* dst
     size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
     dst[g] = F::canon(F::tmul(tbl[(g & tbl_mask) * tstride + toff], src[g]));
-}
-
-// dst[b*m + 2i]   = u0[i] + xe[i]*v0[i]                (src block  = [u0 | v0])
-// dst[b*m + 2i+1] = w1[i]*U1[i] + w1x[i]*V1[i]         (work block = [U1 | V1], normalised)
-template <class F>
-__global__ __launch_bounds__(kBlock) void k_enter_combine(typename F::elem* __restrict__ dst,
-                                                           const typename F::elem* __restrict__ src,
-                                                           const typename F::elem* __restrict__ work,
-                                                           const typename F::telem* __restrict__ xe,
-                                                           const typename F::telem* __restrict__ w1,
-                                                           const typename F::telem* __restrict__ w1x,
-                                                           uint32_t log_e, size_t npairs) {
-    size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= npairs) return;
-    size_t e = (size_t)1 << log_e;
-    size_t i = g & (e - 1);
-    size_t base = (g >> log_e) << (log_e + 1);
-    typename F::elem u0 = src[base + i], v0 = src[base + e + i];
-    typename F::elem U1 = work[base + i], V1 = work[base + e + i];
-    typename F::elem even = F::tmul_add(xe[i], v0, u0);
-    typename F::elem odd = F::tmul_add(w1x[i], V1, F::tmul(w1[i], U1));
-    dst[base + 2 * i] = F::canon(even);
-    dst[base + 2 * i + 1] = F::canon(odd);
 }
 
 // ---------------------------------------------------------------------------------------------

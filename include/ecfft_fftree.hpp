@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
+#include <string>
 #include <vector>
 #include "ecfft_hip.h"
 
@@ -28,6 +29,9 @@ inline void check(int rc) {
     }
 }
 
+inline unsigned log2_floor(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
+inline void require(bool cond, const char* what) { if (!cond) throw std::invalid_argument(what); }
+
 template <class F>
 class FFTree {
 public:
@@ -47,6 +51,9 @@ public:
     }
     // FFTree::new (src/fftree.rs:42-70): maps as 3 numerator + 3 denominator coefficients each
     static FFTree from_leaves(const std::vector<Elem>& leaves, const std::vector<Elem>& num3, const std::vector<Elem>& den3, int device = 0) {
+        // the C ABI reads 3*log2(n) numerator and denominator coefficients: a short vector would be a host out-of-bounds read
+        require(!leaves.empty() && (leaves.size() & (leaves.size() - 1)) == 0, "leaves: length must be a power of two");
+        require(num3.size() == 3 * (size_t)log2_floor(leaves.size()) && den3.size() == num3.size(), "rational maps: need 3*log2(n) numerator and denominator coefficients");
         ecfft_ctx* c = nullptr;
         check(ecfft_fftree_new(F::id, leaves.data(), leaves.size(), num3.data(), den3.data(), device, &c));
         return FFTree(c);
@@ -77,6 +84,7 @@ public:
     std::vector<Elem> redc_z0(const std::vector<Elem>& evals, const std::vector<Elem>& a) const { return redc(evals, a, Moiety::S0); }
     std::vector<Elem> redc_z1(const std::vector<Elem>& evals, const std::vector<Elem>& a) const { return redc(evals, a, Moiety::S1); }
     std::vector<Elem> modular_reduce(const std::vector<Elem>& evals, const std::vector<Elem>& a, const std::vector<Elem>& c) const {
+        require(a.size() == evals.size() && c.size() == evals.size(), "modular_reduce: a and c must have evals.len() entries");
         std::vector<Elem> out(evals.size());
         check(ecfft_modular_reduce(ctx_, evals.data(), a.data(), c.data(), out.data(), evals.size(), ECFFT_MEM_HOST, nullptr));
         return out;
@@ -108,6 +116,7 @@ public:
 
 private:
     std::vector<Elem> redc(const std::vector<Elem>& evals, const std::vector<Elem>& a, Moiety m) const {
+        require(a.size() == evals.size(), "redc: a must have evals.len() entries");
         std::vector<Elem> out(evals.size());
         check(ecfft_redc(ctx_, evals.data(), a.data(), out.data(), evals.size(), (int)m, ECFFT_MEM_HOST, nullptr));
         return out;

@@ -39,7 +39,8 @@ def test_sharded_transforms_with_hip_ops(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("secp256k1", 1 << 8, 2)])
+@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("secp256k1", 1 << 8, 2),
+                                           ("secp256k1", 1 << 22, 3)])   # last: BASELINE configs[3] size, P = 8
 def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
     """the HIP shard kernels (cyclic top stages with strided tables, block-local fused stages with
     k >= log P) emulating P ranks sequentially on one GPU == the single-GPU EXTEND, bit for bit"""
@@ -50,6 +51,8 @@ def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
     rng = np.random.default_rng(5)
     if field == "m31":
         x = rng.integers(0, 2**31 - 1, e, dtype=np.uint32)
+    elif e > (1 << 16):                                   # any 256-bit pattern below p is a valid element (top bit cleared)
+        x = rng.integers(0, 2**64, size=(e, 4), dtype=np.uint64); x[:, 3] >>= np.uint64(1)
     else:
         x = oracle_mod.field(field).from_ints([int.from_bytes(rng.bytes(32), "little") % (2**256 - 2**32 - 977) for _ in range(e)])
     for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):

@@ -38,6 +38,9 @@ def rand_elems(F, n, seed):
     rng = np.random.default_rng(seed)
     if F.limbs == 1:
         return rng.integers(0, 2**31 - 1, n, dtype=np.uint32)
+    if n > (1 << 16):          # large arrays: any 256-bit pattern below p is a valid element (top bit cleared), no Python loop
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        return a
     p = 2**256 - 2**32 - 977
     return F.from_ints([int.from_bytes(rng.bytes(32), "little") % p for _ in range(n)])
 
@@ -216,6 +219,48 @@ def test_full_size_properties(gpu, gpu_tree, oracle_mod, field, log_n):
     el = t.enter(lo)
     assert np.array_equal(t.extend(el[0::2].copy(), gpu.Moiety.S1), el[1::2])
     assert np.array_equal(t.extend(el[1::2].copy(), gpu.Moiety.S0), el[0::2])
+
+
+def test_config5_m31_2e24(gpu, gpu_tree, oracle_mod):
+    """BASELINE.json configs[4]: M31 n = 2^24 ENTER on one GPU — the size where the tile / column-pass counts and the
+    32-bit index arithmetic of the LDS kernels change regime.  ENTER is pinned by naive Horner evaluation (oracle) at
+    individual leaves; EXIT(ENTER(c)) == c, linearity and the S0 <-> S1 EXTEND property cover the rest of the array."""
+    n = 1 << 24
+    F = oracle_mod.field("m31")
+    t = gpu_tree("m31", n)
+    a, b = rand_elems(F, n, 0x5EED0004), rand_elems(F, n, 0x5EED0014)
+    ea, eb = t.enter(a), t.enter(b)
+    leaves = t.leaves()
+    idx = np.array([0, 1, 2, 3, n // 2 - 1, n // 2, n - 2, n - 1, 8191, 8192, 1234567, 16777213 % n, 9999999])
+    assert np.array_equal(ea[idx], F.horner(a, leaves[idx]))
+    assert np.array_equal(eb[idx], F.horner(b, leaves[idx]))
+    assert np.array_equal(t.exit(ea), a)
+    assert np.array_equal(t.enter(F.add(a, b)), F.add(ea, eb))
+    r = rand_elems(F, n, 0x5EED0024)                       # EXIT of arbitrary evaluations, inverted by ENTER
+    assert np.array_equal(t.enter(t.exit(r)), r)
+    lo = a.copy(); lo[n // 2:] = 0                         # degree < n/2: S0 values determine S1 values
+    el = t.enter(lo)
+    assert np.array_equal(t.extend(el[0::2].copy(), gpu.Moiety.S1), el[1::2])
+    assert np.array_equal(t.extend(el[1::2].copy(), gpu.Moiety.S0), el[0::2])
+
+
+def test_secp_2e18_vs_oracle(gpu, gpu_tree, oracle_mod):
+    """secp256k1 n = 2^18 against the CPU oracle, element for element: ENTER, EXIT of ARBITRARY evaluations (not only of
+    ENTER outputs — a wrong-but-self-inverse top-level pass would survive a round-trip test) and EXTEND both ways.  2^18 has
+    two levels above the fused low-level kernels' reach with column passes and the two-halves schedule active."""
+    n = 1 << 18
+    F = oracle_mod.field("secp256k1")
+    ot = F.build_fftree(n)
+    t = gpu_tree("secp256k1", n)
+    c = rand_elems(F, n, 0x5EED0018)
+    ev = ot.enter(c)
+    assert np.array_equal(t.enter(c), ev)
+    assert np.array_equal(t.exit(ev), c)
+    r = rand_elems(F, n, 0x5EED0028)
+    assert np.array_equal(t.exit(r), ot.exit(r))
+    h = r[: n // 2]
+    assert np.array_equal(t.extend(h, gpu.Moiety.S1), ot.extend(h, oracle_mod.S1))
+    assert np.array_equal(t.extend(h, gpu.Moiety.S0), ot.extend(h, oracle_mod.S0))
 
 
 def test_config4_extend_2e22(gpu, gpu_tree, oracle_mod):
