@@ -19,7 +19,9 @@ struct M31 {
     __host__ __device__ static inline bool is_zero(elem a) { return a == 0; }
     __host__ __device__ static inline bool eq(elem a, elem b) { return a == b; }
     __host__ __device__ static inline elem add(elem a, elem b) { uint32_t s = a + b; return s >= P ? s - P : s; }
-    __host__ __device__ static inline elem sub(elem a, elem b) { return a >= b ? a - b : a + P - b; }
+    // a - b for a, b in [0, p]: d = a - b wraps to >= 2^32 - p exactly when a < b, and then d + p (mod 2^32) is the small
+    // representative — min(d, d + p) picks the right one in 3 plain VALU instructions with no compare / VCC
+    __host__ __device__ static inline elem sub(elem a, elem b) { uint32_t d = a - b, w = d + P; return d < w ? d : w; }
     __host__ __device__ static inline elem neg(elem a) { return a ? P - a : 0; }
     __host__ __device__ static inline elem red64(uint64_t t) {  // t < 2^62 + 2^31 (a product of residues plus a residue)
         uint32_t lo = (uint32_t)t & P, hi = (uint32_t)(t >> 31);     // hi <= 2^31, so lo + hi < 2^32
@@ -37,8 +39,9 @@ struct M31 {
     // maps [0, p] x [0, p] into [0, p] as written.  Every value that leaves a kernel for HBM goes through canon().
     __host__ __device__ static inline elem red64_lazy(uint64_t t) {
         uint32_t lo = (uint32_t)t & P, hi = (uint32_t)(t >> 31);
-        uint32_t r = lo + hi;
-        return (r & P) + (r >> 31);
+        uint32_t r = lo + hi;                     // <= 2^32 - 2
+        uint32_t d = r - P;                       // second fold as subtract + unsigned min (2 plain VALU instructions instead of
+        return d < r ? d : r;                     // and / shift / add): r >= p -> r - p in [0, p]; r < p -> the difference wraps, keep r
     }
     __host__ __device__ static inline elem tmul(telem t, elem x) { return red64_lazy((uint64_t)t * x); }
     __host__ __device__ static inline elem tmul_add(telem t, elem x, elem c) { return red64_lazy((uint64_t)t * x + c); }

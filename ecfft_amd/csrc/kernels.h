@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 
 namespace ecfft {
 
@@ -133,6 +134,154 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tile load / store for 4-byte fields, four consecutive elements ("quad") at a time.  The element-at-a-time loops of the
+// generic kernels compile to a loop that waits for every 4-byte load before issuing the next one — 16 serial HBM round
+// trips per thread for an 8192-element tile.  Here a thread issues ALL its 16-byte loads (data, strided gathers, operator
+// tables) first, then computes, then stores 16 bytes per instruction.  `pos_of(j)` maps the LDS index j (a multiple of 4,
+// j..j+3 contiguous in LDS) to the position of the quad in the work buffer (contiguous there too).
+// Preconditions checked by vio_ok(): e >= 4, 16-byte aligned pointers, strides as produced by the level drivers.
+// ---------------------------------------------------------------------------------------------
+struct Quad { uint32_t v[4]; };
+__device__ __forceinline__ Quad ldq(const uint32_t* p) { uint4 t = *reinterpret_cast<const uint4*>(p); return Quad{{t.x, t.y, t.z, t.w}}; }
+__device__ __forceinline__ void stq(uint32_t* p, const Quad& q) { *reinterpret_cast<uint4*>(p) = make_uint4(q.v[0], q.v[1], q.v[2], q.v[3]); }
+// four elements at p[stride*k + off], k = 0..3, stride 1 (off 0) or 2 (off 0 / 1)
+__device__ __forceinline__ Quad ldq_strided(const uint32_t* p, uint32_t stride, uint32_t off) {
+    if (stride == 1) return ldq(p);
+    uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 4);
+    return off ? Quad{{a.y, a.w, b.y, b.w}} : Quad{{a.x, a.z, b.x, b.z}};
+}
+template <class F>
+__device__ __forceinline__ bool vio_ok(const IoDesc<F>& io, uint32_t log_e) {
+    if constexpr (sizeof(typename F::elem) != 4) return false;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool ok = log_e >= 2 && al(io.src) && al(io.dst) && ((io.src_stride == 1 && io.src_off == 0) || (io.src_stride == 2 && io.src_off < 2));
+    if (io.ld_mode == LD_SCALE) ok = ok && al(io.ld_tbl);
+    if (io.st_mode == ST_SCALE || io.st_mode == ST_AXPBY || io.st_mode == ST_EXIT_SPLIT) ok = ok && al(io.st_a);
+    if (io.st_mode == ST_AXPBY || io.st_mode == ST_EXIT_SPLIT) ok = ok && al(io.st_b) && al(io.aux) && ((io.aux_stride == 1 && io.aux_off == 0) || (io.aux_stride == 2 && io.aux_off < 2));
+    if (io.st_mode == ST_AXPBY && io.aux_out) ok = ok && al(io.aux_out);
+    if (io.st_mode == ST_EXIT_SPLIT) ok = ok && io.aux_stride == 2 && io.aux_off == 0;
+    return ok;
+}
+template <class F, int NQ, int BLK, class PosFn>
+__device__ __forceinline__ void vio_load(const IoDesc<F>& io, size_t emask, typename F::elem* tile, PosFn pos_of, uint32_t tid) {
+    Quad d[NQ], t[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); d[c] = ldq_strided(io.src + (size_t)io.src_stride * pos, io.src_stride, io.src_off); }
+    if (io.ld_mode == LD_SCALE) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); t[c] = ldq(io.ld_tbl + (pos & emask)); }
+#pragma unroll
+        for (int c = 0; c < NQ; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[c].v[k] = F::tmul(t[c].v[k], d[c].v[k]);
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) stq(tile + 4u * (tid + (uint32_t)c * BLK), d[c]);
+}
+template <class F, int NQ, int BLK, class PosFn>
+__device__ __forceinline__ void vio_store(const IoDesc<F>& io, uint32_t log_e, const typename F::elem* tile, PosFn pos_of, uint32_t tid) {
+    const size_t e = (size_t)1 << log_e, emask = e - 1;
+    Quad x[NQ], a[NQ], b[NQ], y[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) x[c] = ldq(tile + 4u * (tid + (uint32_t)c * BLK));
+    const int m = io.st_mode;
+    if (m != ST_PLAIN) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); a[c] = ldq(io.st_a + (pos & emask)); }
+    }
+    if (m == ST_AXPBY || m == ST_EXIT_SPLIT) {
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+            const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK));
+            b[c] = ldq(io.st_b + (pos & emask));
+            y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK));
+        Quad r, r2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (m == ST_PLAIN) r.v[k] = F::canon(x[c].v[k]);
+            else if (m == ST_SCALE) r.v[k] = F::canon(F::tmul(a[c].v[k], x[c].v[k]));
+            else if (m == ST_AXPBY) r.v[k] = F::canon(F::tmul_add(a[c].v[k], x[c].v[k], F::tmul(b[c].v[k], y[c].v[k])));
+            else { r.v[k] = F::canon(F::tmul(a[c].v[k], x[c].v[k])); r2.v[k] = F::canon(F::tmul(b[c].v[k], F::sub(y[c].v[k], r.v[k]))); }
+        }
+        if (m == ST_EXIT_SPLIT) {
+            const size_t bs = (pos >> log_e) << (log_e + 1), i = pos & emask;
+            stq(io.dst + bs + i, r); stq(io.dst + bs + e + i, r2);
+        } else {
+            stq(io.dst + pos, r);
+            if (m == ST_AXPBY && io.aux_out) stq(io.aux_out + pos, r);
+        }
+    }
+}
+
+// io_mid on quads, in place in LDS: the store operator of one EXTEND core (ST_PLAIN / ST_SCALE / ST_AXPBY, side output
+// aux_out written) followed by the load operator of the next (LD_PLAIN / LD_SCALE)
+template <class F, int NQ, int BLK, class PosFn>
+__device__ __forceinline__ void vio_mid(const IoDesc<F>& io, uint32_t log_e, typename F::elem* tile, PosFn pos_of, uint32_t tid) {
+    const size_t emask = ((size_t)1 << log_e) - 1;
+    Quad x[NQ], a[NQ], b[NQ], y[NQ], l[NQ];
+    const int m = io.st_mode;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)), i = pos & emask;
+        x[c] = ldq(tile + 4u * (tid + (uint32_t)c * BLK));
+        if (m != ST_PLAIN) a[c] = ldq(io.st_a + i);
+        if (m == ST_AXPBY) { b[c] = ldq(io.st_b + i); y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off); }
+        if (io.ld_mode == LD_SCALE) l[c] = ldq(io.ld_tbl + i);
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK));
+        Quad r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t v = x[c].v[k];
+            if (m == ST_SCALE) v = F::tmul(a[c].v[k], v);
+            else if (m == ST_AXPBY) v = F::canon(F::tmul_add(a[c].v[k], v, F::tmul(b[c].v[k], y[c].v[k])));
+            r.v[k] = v;
+        }
+        if (m == ST_AXPBY && io.aux_out) stq(io.aux_out + pos, r);
+        if (io.ld_mode == LD_SCALE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.v[k] = F::tmul(l[c].v[k], r.v[k]);
+        }
+        stq(tile + 4u * (tid + (uint32_t)c * BLK), r);
+    }
+}
+
+// ENTER combine (ST_ENTER) on quads: NQ quads of pairs per thread; for quad c: ju / jv = LDS indices of U1~ / V1~, i = pair
+// index inside the block (multiple of 4), bb = position of the block [u0 | v0] in the level's input / output
+template <class F, int NQ, class IdxFn>
+__device__ __forceinline__ void vio_enter_store(const typename F::elem* tile, const typename F::elem* __restrict__ src, typename F::elem* __restrict__ dst,
+                                                const typename F::telem* __restrict__ xe, const typename F::telem* __restrict__ w1,
+                                                const typename F::telem* __restrict__ w1x, size_t e, IdxFn idx) {
+    Quad u0[NQ], v0[NQ], tx[NQ], tw[NQ], twx[NQ], U[NQ], V[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        uint32_t ju, jv; size_t i, bb; idx(c, ju, jv, i, bb);
+        u0[c] = ldq(src + bb + i); v0[c] = ldq(src + bb + e + i);
+        tx[c] = ldq(xe + i); tw[c] = ldq(w1 + i); twx[c] = ldq(w1x + i);
+        U[c] = ldq(tile + ju); V[c] = ldq(tile + jv);
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        uint32_t ju, jv; size_t i, bb; idx(c, ju, jv, i, bb);
+        Quad lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ev = F::canon(F::tmul_add(tx[c].v[k], v0[c].v[k], u0[c].v[k]));
+            const uint32_t od = F::canon(F::tmul_add(twx[c].v[k], V[c].v[k], F::tmul(tw[c].v[k], U[c].v[k])));
+            if (k < 2) { lo.v[2 * k] = ev; lo.v[2 * k + 1] = od; } else { hi.v[2 * (k - 2)] = ev; hi.v[2 * (k - 2) + 1] = od; }
+        }
+        stq(dst + bb + 2 * i, lo); stq(dst + bb + 2 * i + 4, hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-fused butterfly stages, "row kernel".  One workgroup owns a contiguous tile of 2^log_tile
 // elements (<= 64 KiB of LDS: 2048 secp256k1 / 16384 M31 elements), loads it once, runs every
 // decompose stage k in [k_first, log e) and then every recombine stage back down to k_first in LDS,
@@ -193,6 +342,154 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident multi-stage engine for 4-byte fields (M31).  A 4-byte element leaves most of the register file
+// idle in the one-stage-per-LDS-round-trip sweeps above, and rocprofv3 showed the M31 row kernel waiting, not issuing
+// (51 % of wave-cycles in s_waitcnt / s_barrier, one VALU instruction per 5.4 cycles per SIMD): every sweep paid a
+// barrier, an LDS round trip and a dependent L2 table load for 14-17 arithmetic instructions per pair.  Here a thread
+// keeps EPT = 16 (or 8) elements in registers and runs NS = 1..3 consecutive stages on them per LDS round trip
+// ("radix-2^NS step": groups of 2^NS elements spaced by the smallest pair distance of the step), the table constants of
+// the whole step are requested BEFORE the barrier that publishes the previous step (they do not depend on the data), and
+// the lowest log2(EPT) decompose stages, the merged innermost stage and the first log2(EPT) recombine stages run on EPT
+// consecutive elements in one visit with wave-uniform (scalar) table constants.  25 sweeps of an 8192-element tile become
+// 7 visits.
+// ---------------------------------------------------------------------------------------------
+template <class F, bool DEC>
+__device__ __forceinline__ void bfly(typename F::elem& a, typename F::elem& b, const typename F::telem& t0, const typename F::telem& t1) {
+    using E = typename F::elem;
+    if (DEC) { E q1 = F::tmul(t1, F::sub(b, a)); a = F::tmul_add(t0, q1, a); b = q1; }
+    else { E o0 = F::tmul_add(t0, b, a), o1 = F::tmul_add(t1, b, a); a = o0; b = o1; }
+}
+
+// NS stages on NG groups of 2^NS elements: group g = LDS positions pbase[g] + j*pstride (j < 2^NS).  Stage s' < NS pairs
+// (j, j + 2^s') and reads table entry (e - 2*(tstride << s')) + tbase[g] + (j mod 2^s')*tstride of ta / tb.
+// DEC runs s' = NS-1 .. 0 (large distance first), recombine 0 .. NS-1.  Starts with the barrier that makes the previous
+// step's LDS writes visible (after the table loads have been issued); does NOT end with one.
+template <class F, int NS, bool DEC, int NG>
+__device__ __forceinline__ void radix_step(typename F::elem* a, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                           uint32_t e, const uint32_t (&pbase)[NG], uint32_t pstride, const uint32_t (&tbase)[NG], uint32_t tstride) {
+    // all table offsets are 32-bit (tables of one tree have < 2^31 entries): uniform base pointer + 32-bit lane offset
+    using E = typename F::elem;
+    using TE = typename F::telem;
+    constexpr int G = 1 << NS;
+    TE t0[NG][G - 1], t1[NG][G - 1];                        // stage s' occupies [2^s' - 1, 2^(s'+1) - 1)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            const uint32_t off = e - 2 * (tstride << sp) + tbase[g];
+#pragma unroll
+            for (int m = 0; m < (1 << sp); ++m) { t0[g][(1 << sp) - 1 + m] = ta[off + (uint32_t)m * tstride]; t1[g][(1 << sp) - 1 + m] = tb[off + (uint32_t)m * tstride]; }
+        }
+    }
+    __syncthreads();
+    E x[NG][G];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < G; ++j) x[g][j] = a[pbase[g] + (uint32_t)j * pstride];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const int sp = DEC ? NS - 1 - st : st;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (!(j & (1 << sp))) bfly<F, DEC>(x[g][j], x[g][j + (1 << sp)], t0[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))], t1[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))]);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < G; ++j) a[pbase[g] + (uint32_t)j * pstride] = x[g][j];
+}
+
+// `cnt` consecutive stages whose SMALLEST pair distance is 2^lh_low elements of a flat array (row layout: table entry =
+// position mod pair distance), in radix-8 steps plus a radix-4 / radix-2 remainder.  DEC: lh_low + cnt - 1 down to lh_low.
+template <class F, bool DEC, int EPT, int BLK>
+__device__ __forceinline__ void flat_stages(typename F::elem* a, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                            uint32_t e, uint32_t lh_low, uint32_t cnt, uint32_t tid) {
+    // chunk sizes: as many 3s as possible, remainder first for DEC / last for recombine does not matter for correctness as
+    // long as the order of stages is monotone; the chunks are walked from the far end for DEC
+    uint32_t done = 0;
+    while (done < cnt) {
+        uint32_t ns = cnt - done >= 3 ? 3 : cnt - done;
+        // DEC walks distances downwards: this chunk covers lh in [top - ns + 1, top], top = lh_low + cnt - 1 - done
+        const uint32_t lo = DEC ? lh_low + cnt - done - ns : lh_low + done;
+        const uint32_t hl = 1u << lo;
+        auto run = [&](auto NSc) {
+            constexpr int NS = decltype(NSc)::value;
+            constexpr int NG = EPT >> NS;
+            uint32_t pb[NG], tb0[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t q = tid + (uint32_t)BLK * g, i0 = q & (hl - 1);
+                pb[g] = ((q >> lo) << (lo + NS)) | i0; tb0[g] = i0;
+            }
+            radix_step<F, NS, DEC, NG>(a, ta, tb, e, pb, hl, tb0, hl);
+        };
+        if (ns == 3) run(std::integral_constant<int, 3>{}); else if (ns == 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
+        done += ns;
+    }
+}
+
+// the lowest stages (pair distance < EPT) on EPT consecutive elements per thread: decompose lh = min(le, LOG_EPT)-1 .. 1, the
+// merged innermost pair (h = 1), recombine 1 .. min(le, LOG_EPT)-1.  All table constants are wave-uniform.  Begins with a barrier.
+template <class F, int EPT, int BLK>
+__device__ __forceinline__ void tail_stages(typename F::elem* a, const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
+                                            const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                            const typename F::telem* __restrict__ inner, uint32_t e, uint32_t le, uint32_t tid) {
+    using E = typename F::elem;
+    static_assert(sizeof(E) == 4 && (EPT == 16 || EPT == 8), "4-byte fields, 8 or 16 elements per thread");
+    constexpr int LOG_EPT = EPT == 16 ? 4 : 3;
+    __syncthreads();
+    if (le == 0) return;
+    E x[EPT];
+    uint4* va = reinterpret_cast<uint4*>(a + (size_t)tid * EPT);
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) { uint4 v = va[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+#pragma unroll
+    for (int lh = LOG_EPT - 1; lh >= 1; --lh) {
+        if ((uint32_t)lh < le) {
+            const uint32_t off = e - 2 * (1u << lh);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+                if (!(j & (1 << lh))) bfly<F, true>(x[j], x[j + (1 << lh)], np0[off + (j & ((1 << lh) - 1))], dinv[off + (j & ((1 << lh) - 1))]);
+        }
+    }
+    {
+        const typename F::telem c0 = inner[0], c1 = inner[1];
+#pragma unroll
+        for (int j = 0; j < EPT; j += 2) { E d = F::sub(x[j + 1], x[j]); E o0 = F::tmul_add(c0, d, x[j]); x[j + 1] = F::tmul_add(c1, d, x[j]); x[j] = o0; }
+    }
+#pragma unroll
+    for (int lh = 1; lh < LOG_EPT; ++lh) {
+        if ((uint32_t)lh < le) {
+            const uint32_t off = e - 2 * (1u << lh);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j)
+                if (!(j & (1 << lh))) bfly<F, false>(x[j], x[j + (1 << lh)], p0[off + (j & ((1 << lh) - 1))], p1[off + (j & ((1 << lh) - 1))]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) va[q] = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// every in-tile stage of an EXTEND core on BLK*EPT LDS elements = vectors of length e laid end to end (or, for e larger
+// than the tile, a tile-aligned piece of one: then only the stages with pair distance below 2^log_span = tile run here).
+// Decompose from distance 2^(log_span-1) down, merged innermost pair, recombine back up.  Starts with a barrier, ends with one.
+template <class F, int EPT, int BLK>
+__device__ __forceinline__ void lds_extend_fast(typename F::elem* a, const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
+                                                const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                                const typename F::telem* __restrict__ inner, size_t e64, uint32_t log_span, uint32_t tid) {
+    const uint32_t e = (uint32_t)e64;
+    constexpr uint32_t LOG_EPT = EPT == 16 ? 4 : 3;
+    const uint32_t upper = log_span > LOG_EPT ? log_span - LOG_EPT : 0;      // stages with pair distance >= EPT
+    if (upper) flat_stages<F, true, EPT, BLK>(a, np0, dinv, e, LOG_EPT, upper, tid);
+    tail_stages<F, EPT, BLK>(a, np0, dinv, p0, p1, inner, e, log_span, tid);
+    if (upper) flat_stages<F, false, EPT, BLK>(a, p0, p1, e, LOG_EPT, upper, tid);
+    __syncthreads();
+}
+
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
 __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
                                                            const typename F::telem* __restrict__ np0,
@@ -208,10 +505,23 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const uint32_t T = 1u << log_tile, tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x << log_tile;
     const size_t e = (size_t)1 << log_e, emask = e - 1;
+    constexpr bool kFast = sizeof(E) == 4 && LOG_TILE_CT > 0 && ((1u << (LOG_TILE_CT > 0 ? LOG_TILE_CT : 0)) % (kBlockRow * 16)) == 0;
+    constexpr int kNQ = kFast ? (1 << (LOG_TILE_CT > 0 ? LOG_TILE_CT : 2)) / (4 * kBlockRow) : 1;
+    bool vio = false;
+    if constexpr (kFast) vio = vio_ok<F>(io, log_e);
+    if constexpr (kFast) { if (vio) vio_load<F, kNQ, kBlockRow>(io, emask, tile, [=](uint32_t j) { return base + j; }, tid); }
+    if (!vio) {
 #pragma unroll
-    for (uint32_t j = tid; j < T; j += kBlockRow) tile[j] = io_load<F>(io, base + j, emask);
+        for (uint32_t j = tid; j < T; j += kBlockRow) tile[j] = io_load<F>(io, base + j, emask);
+    }
     __syncthreads();
     const uint32_t npairs = T >> 1;
+    if constexpr (kFast) {
+        // register-resident multi-stage engine, 8192 elements per call (a 64 KiB ST_ENTER tile is two independent halves)
+#pragma unroll 1
+        for (uint32_t o = 0; o < T; o += kBlockRow * 16)
+            lds_extend_fast<F, 16, kBlockRow>(tile + o, np0, dinv, p0, p1, inner, e, log_e - k_first, tid);
+    } else {
     // stages k_first .. log_e-2 (h >= 2); the two innermost stages (decompose h=1, recombine h=1) act on the
     // same pairs back to back and are merged into out_j = a + c_j*(b - a): 2 multiplies instead of 4
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
@@ -236,8 +546,19 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
     }
+    }
     if (io.st_mode == ST_ENTER) {
         // the tile holds whole [U1~ | V1~] blocks (2e <= T): combine them with the level's input and store interleaved
+        if constexpr (kFast) {
+            auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+            if (log_e >= 2 && al(io.aux) && al(io.dst) && al(io.st_a) && al(io.st_b) && al(io.st_c)) {
+                vio_enter_store<F, kNQ / 2>(tile, io.aux, io.dst, io.st_a, io.st_c, io.st_b, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
+                    const uint32_t g = 4u * (tid + (uint32_t)c * kBlockRow), ii = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
+                    ju = lb + ii; jv = lb + (uint32_t)e + ii; i = ii; bb = base + lb;
+                });
+                return;
+            }
+        }
         for (uint32_t g = tid; g < npairs; g += kBlockRow) {
             const uint32_t i = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
             const size_t bb = base + lb;
@@ -249,6 +570,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         }
         return;
     }
+    if constexpr (kFast) { if (vio) { vio_store<F, kNQ, kBlockRow>(io, log_e, tile, [=](uint32_t j) { return base + j; }, tid); return; } }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
 }
@@ -301,6 +623,52 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
     }
 }
 
+// The R stages of a column tile (2^R rows x C columns in LDS, row distance 2^s at stage k = kb - s; table entry
+// ((row mod 2^s) << log_hs) + c0 + column, table base e - 2*(hs << s)).  DECOMPOSE runs s = R-1 .. 0, recombine 0 .. R-1.
+// 4-byte fields with exactly 16 elements per thread use the register-resident radix steps (up to 3 stages per LDS round
+// trip, table constants requested before the barrier); everything else sweeps one stage at a time.  Ends with a barrier.
+template <class F, bool DEC>
+__device__ __forceinline__ void col_stages(typename F::elem* tile, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                           uint32_t R, uint32_t log_c, uint32_t log_hs, size_t c0, size_t e, uint32_t tid, uint32_t halves = 1) {
+    // halves = 2: two such tiles back to back in LDS that use the same table entries (k_stages_col_enter)
+    using E = typename F::elem;
+    const uint32_t C = 1u << log_c, T = C << R;
+    if constexpr (sizeof(E) == 4 && ECFFT_COL_PAD == 0) {
+        if (T == kBlockLds * 16) {
+          for (uint32_t hf = 0; hf < halves; ++hf, tile += T) {
+            uint32_t done = 0;
+            while (done < R) {
+                const uint32_t ns = R - done >= 3 ? 3 : R - done;
+                const uint32_t slo = DEC ? R - done - ns : done;              // lowest stage index s of this chunk
+                auto run = [&](auto NSc) {
+                    constexpr int NS = decltype(NSc)::value;
+                    constexpr int NG = 16 >> NS;
+                    uint32_t pb[NG], tb0[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const uint32_t q = tid + (uint32_t)kBlockLds * g, cc = q & (C - 1), rq = q >> log_c;
+                        const uint32_t rlow = rq & ((1u << slo) - 1), rb = ((rq >> slo) << (slo + NS)) | rlow;
+                        pb[g] = (rb << log_c) + cc; tb0[g] = (rlow << log_hs) + (uint32_t)c0 + cc;
+                    }
+                    radix_step<F, NS, DEC, NG>(tile, ta, tb, (uint32_t)e, pb, C << slo, tb0, (1u << log_hs) << slo);
+                };
+                if (ns == 3) run(std::integral_constant<int, 3>{}); else if (ns == 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
+                done += ns;
+            }
+          }
+            __syncthreads();
+            return;
+        }
+    }
+    const size_t hs = (size_t)1 << log_hs;
+    for (uint32_t st = 0; st < R; ++st) {
+        const uint32_t sft = DEC ? R - 1 - st : st;
+        const size_t h = hs << sft;
+        col_stage_sweep<F, DEC>(tile, ta + (e - 2 * h), tb + (e - 2 * h), sft, log_c, log_hs, c0, (halves * T) >> 1, tid);   // pairs never cross a tile (row distance < 2^R)
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-fused butterfly stages, "column kernel": the R = kb-ka+1 consecutive stages ka..kb whose pair
 // distances (h_ka = hs*2^(R-1) ... h_kb = hs) are too large for a contiguous tile.  A workgroup
@@ -326,20 +694,21 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
     const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t B = (blk << (log_hs + R)) + (chunk << log_c);       // position of (row 0, col 0)
     const size_t c0 = (chunk << log_c);                              // column offset inside the hs-block
+    constexpr bool kFast = sizeof(E) == 4 && ECFFT_COL_PAD == 0 && LOG_TILE_CT > 0 && (1u << (LOG_TILE_CT > 0 ? LOG_TILE_CT : 0)) == kBlockLds * 16;
+    bool vio = false;
+    if constexpr (kFast) vio = log_c >= 2 && vio_ok<F>(io, log_e);
+    auto pos_of = [=](uint32_t j) { return B + ((size_t)(j >> log_c) << log_hs) + (j & (C - 1)); };
+    if constexpr (kFast) { if (vio) vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid); }
+    if (!vio) {
 #pragma unroll
-    for (uint32_t j = tid; j < T; j += kBlockLds) {
-        uint32_t r = j >> log_c, cc = j & (C - 1);
-        tile[r * col_row_stride<E>(C) + cc] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
+        for (uint32_t j = tid; j < T; j += kBlockLds) {
+            uint32_t r = j >> log_c, cc = j & (C - 1);
+            tile[r * col_row_stride<E>(C) + cc] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
+        }
     }
     __syncthreads();
-    const uint32_t npairs = T >> 1;
-    for (uint32_t st = 0; st < R; ++st) {
-        const uint32_t k = DECOMPOSE ? ka + st : kb - st;
-        const uint32_t s = kb - k, d = 1u << s;                      // row distance of the pair
-        const size_t h = hs << s;
-        col_stage_sweep<F, DECOMPOSE>(tile, ta + (e - 2 * h), tb + (e - 2 * h), s, log_c, log_hs, c0, npairs, tid);
-        __syncthreads();
-    }
+    col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid);
+    if constexpr (kFast) { if (vio) { vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid); return; } }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
@@ -371,30 +740,36 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
     const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t B = (blk << (log_hs + R)) + (chunk << log_c);
     const size_t c0 = (chunk << log_c);
+    auto pos_of = [=](uint32_t j) { return B + ((size_t)(j >> log_c) << log_hs) + (j & (C - 1)); };
+    bool vio = false;
+    if constexpr (sizeof(E) == 4 && ECFFT_COL_PAD == 0) {
+        IoDesc<F> chk = io; chk.src_stride = 1; chk.src_off = 0;           // this kernel reads src plainly and stores plainly
+        const int m = io.st_mode;
+        vio = T == kBlockLds * 16 && log_c >= 2 && (m == ST_PLAIN || m == ST_SCALE || m == ST_AXPBY) && vio_ok<F>(chk, log_e);
+        if (vio) {
+            IoDesc<F> pl = io; pl.src_stride = 1; pl.src_off = 0; pl.ld_mode = LD_PLAIN; pl.st_mode = ST_PLAIN;
+            vio_load<F, 4, kBlockLds>(pl, emask, tile, pos_of, tid);
+            __syncthreads();
+            col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid);
+            vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
+            __syncthreads();
+            col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid);
+            vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid);
+            return;
+        }
+    }
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         tile[r * col_row_stride<E>(C) + cc] = io.src[B + ((size_t)r << log_hs) + cc];
     }
     __syncthreads();
-    const uint32_t npairs = T >> 1;
-    for (uint32_t half = 0; half < 2; ++half) {
-        const bool dec = half == 1;
-        for (uint32_t st = 0; st < R; ++st) {
-            const uint32_t k = dec ? ka + st : kb - st;
-            const uint32_t sft = kb - k, d = 1u << sft;
-            const size_t h = hs << sft;
-            if (dec) col_stage_sweep<F, true>(tile, np0 + (e - 2 * h), dinv + (e - 2 * h), sft, log_c, log_hs, c0, npairs, tid);
-            else col_stage_sweep<F, false>(tile, p0 + (e - 2 * h), p1 + (e - 2 * h), sft, log_c, log_hs, c0, npairs, tid);
-            __syncthreads();
-        }
-        if (!dec) {
-            for (uint32_t j = tid; j < T; j += kBlockLds) {
-                uint32_t r = j >> log_c, cc = j & (C - 1);
-                { const uint32_t q = r * col_row_stride<E>(C) + cc; tile[q] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[q]); }
-            }
-            __syncthreads();
-        }
+    col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid);
+    for (uint32_t j = tid; j < T; j += kBlockLds) {
+        uint32_t r = j >> log_c, cc = j & (C - 1);
+        { const uint32_t q = r * col_row_stride<E>(C) + cc; tile[q] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[q]); }
     }
+    __syncthreads();
+    col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid);
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io.dst[B + ((size_t)r << log_hs) + cc] = F::canon(tile[r * col_row_stride<E>(C) + cc]);
@@ -429,18 +804,37 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_enter
     const size_t b = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t c0 = chunk << log_c;
     const size_t B = (b << (log_e + 1)) + c0;                        // position of (row 0, col 0) of the U vector
+    bool vio = false;
+    if constexpr (sizeof(E) == 4 && ECFFT_COL_PAD == 0) {
+        auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        vio = T == kBlockLds * 32 && log_c >= 2 && al(work) && al(src) && al(dst) && al(xe) && al(w1) && al(w1x);
+        if (vio) {
+            Quad d[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds), r = j >> log_c, cc = j & (C - 1);
+                d[c] = ldq(work + B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) stq(tile + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+            __syncthreads();
+            col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 2);
+            const size_t bb0 = b << (log_e + 1);
+            vio_enter_store<F, 4>(tile, src, dst, xe, w1, w1x, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
+                const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds), r = j >> log_c, cc = j & (C - 1);
+                ju = j; jv = j + (C << R); i = ((size_t)r << log_hs) + c0 + cc; bb = bb0;
+            });
+            return;
+        }
+    }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         const uint32_t r = j >> log_c, cc = j & (C - 1);            // r < 2^(R+1): r >> R selects the vector
         tile[r * RS + cc] = work[B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc];
     }
     __syncthreads();
-    const uint32_t npairs = T >> 1;
-    for (uint32_t st = 0; st < R; ++st) {                            // stage k = kb - st, row distance 2^st
-        const size_t h = hs << st;
-        col_stage_sweep<F, false>(tile, p0 + (e - 2 * h), p1 + (e - 2 * h), st, log_c, log_hs, c0, npairs, tid);
-        __syncthreads();
-    }
+    // the U rows and the V rows are two independent column tiles that read the same table entries
+    col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 2);
 #pragma unroll
     for (uint32_t j = tid; j < (T >> 1); j += kBlockLds) {
         const uint32_t r = j >> log_c, cc = j & (C - 1);
@@ -481,6 +875,11 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
+    if constexpr (sizeof(E) == 4) {
+        // callers have published `a` with a barrier; the engine starts with one of its own and ends with one
+        if (len == kBlockLds * 16) { lds_extend_fast<F, 16, kBlockLds>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
+        if (len == kBlockLds * 8) { lds_extend_fast<F, 8, kBlockLds>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
+    }
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     for (uint32_t k = 0; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
@@ -517,11 +916,72 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
     E* cur = reinterpret_cast<E*>(ecfft_smem);
     E* work = cur + T;
     const size_t base = (size_t)blockIdx.x << log_tile;
-    for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    constexpr bool kQuad = sizeof(E) == 4 && T % (4 * kBlockLds) == 0;     // 4-byte fields: quad-vectorised, loads-first pointwise steps
+    bool qio = false;                                                      // user pointers may be only element-aligned
+    if constexpr (kQuad) qio = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if constexpr (kQuad) {
+        if (qio) {
+            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            Quad d[NQ];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * kBlockLds));
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+        }
+    }
+    if (!qio) {
+        for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    }
     __syncthreads();
     for (uint32_t l = 1; l <= log_tile; ++l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
+        if constexpr (kQuad) {
+            if (le >= 2) {
+                constexpr int NQ = (int)(T / (4 * kBlockLds)), NP = NQ / 2;
+                {
+                    Quad x[NQ], t[NQ];
+                    const typename F::telem* wi = L.winv[0];
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) { const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds); t[c] = ldq(wi + (j & (e - 1))); x[c] = ldq(cur + j); }
+#pragma unroll
+                    for (int c = 0; c < NQ; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul(t[c].v[k], x[c].v[k]);
+                        stq(work + 4u * (tid + (uint32_t)c * kBlockLds), x[c]);
+                    }
+                }
+                __syncthreads();
+                lds_extend_core<F>(work, T, le, L, 0);
+                Quad lo[NP], hi[NP];
+                {
+                    Quad u0[NP], v0[NP], U1[NP], V1[NP], tx[NP], tw[NP], twx[NP];
+                    const typename F::telem *xe = L.xe, *w1 = L.w[1], *w1x = L.w1x;
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+                        const uint32_t g = 4u * (tid + (uint32_t)c * kBlockLds), i = g & (e - 1), bb = (g >> le) << l;
+                        tx[c] = ldq(xe + i); tw[c] = ldq(w1 + i); twx[c] = ldq(w1x + i);
+                        u0[c] = ldq(cur + bb + i); v0[c] = ldq(cur + bb + e + i); U1[c] = ldq(work + bb + i); V1[c] = ldq(work + bb + e + i);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const E ev = F::tmul_add(tx[c].v[k], v0[c].v[k], u0[c].v[k]);
+                            const E od = F::tmul_add(twx[c].v[k], V1[c].v[k], F::tmul(tw[c].v[k], U1[c].v[k]));
+                            if (k < 2) { lo[c].v[2 * k] = ev; lo[c].v[2 * k + 1] = od; } else { hi[c].v[2 * (k - 2)] = ev; hi[c].v[2 * (k - 2) + 1] = od; }
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NP; ++c) {
+                    const uint32_t g = 4u * (tid + (uint32_t)c * kBlockLds), i = g & (e - 1), bb = (g >> le) << l;
+                    stq(cur + bb + 2 * i, lo[c]); stq(cur + bb + 2 * i + 4, hi[c]);
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         for (uint32_t j = tid; j < T; j += kBlockLds) work[j] = F::tmul(L.winv[0][j & (e - 1)], cur[j]);
         __syncthreads();
         lds_extend_core<F>(work, T, le, L, 0);
@@ -543,6 +1003,19 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
         }
         __syncthreads();
     }
+    if constexpr (kQuad) {
+        if (qio) {
+            constexpr int NQ = (int)(T / (4 * kBlockLds));
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * kBlockLds));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q.v[k] = F::canon(q.v[k]);
+                stq(dst + base + 4u * (tid + (uint32_t)c * kBlockLds), q);
+            }
+            return;
+        }
+    }
     for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
 }
 
@@ -561,11 +1034,106 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
     E* G = cur + T;
     E* H = G + nh;
     const size_t base = (size_t)blockIdx.x << log_tile;
-    for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    constexpr bool kQuad = sizeof(E) == 4 && nh % (4 * kBlockLds) == 0;
+    bool qio = false;                                                      // user pointers may be only element-aligned
+    if constexpr (kQuad) qio = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if constexpr (kQuad) {
+        if (qio) {
+            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            Quad d[NQ];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * kBlockLds));
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+        }
+    }
+    if (!qio) {
+        for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+    }
     __syncthreads();
     for (uint32_t l = log_tile; l >= 1; --l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
+        if constexpr (kQuad) {
+            if (le >= 2) {
+                // the level's five pointwise steps on quads of the pair index g (loads first), the four EXTEND cores between them
+                constexpr int NP = (int)(nh / (4 * kBlockLds));
+                auto gq = [=](int c) { return 4u * (tid + (uint32_t)c * kBlockLds); };
+                auto tq = [=](const typename F::telem* t, int c) { return ldq(t + (gq(c) & (e - 1))); };
+                auto evenq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.x, a.z, b.x, b.z}}; };
+                auto oddq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.y, a.w, b.y, b.w}}; };
+                {
+                    Quad t[NP], x[NP];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) { t[c] = tq(L.A1, c); x[c] = evenq(c); }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul(t[c].v[k], x[c].v[k]);
+                        stq(G + gq(c), x[c]);
+                    }
+                }
+                __syncthreads();
+                lds_extend_core<F>(G, nh, le, L, 0);
+                {
+                    Quad ta[NP], tb[NP], x[NP], y[NP];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) { ta[c] = tq(L.NB2, c); tb[c] = tq(L.B1, c); x[c] = ldq(G + gq(c)); y[c] = oddq(c); }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul_add(ta[c].v[k], x[c].v[k], F::tmul(tb[c].v[k], y[c].v[k]));
+                        stq(G + gq(c), x[c]); stq(H + gq(c), x[c]);
+                    }
+                }
+                __syncthreads();
+                lds_extend_core<F>(G, nh, le, L, 1);
+                {
+                    Quad t[NP], x[NP];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) { t[c] = tq(L.C1, c); x[c] = ldq(G + gq(c)); }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul(t[c].v[k], x[c].v[k]);
+                        stq(G + gq(c), x[c]);
+                    }
+                }
+                __syncthreads();
+                lds_extend_core<F>(G, nh, le, L, 0);
+                {
+                    Quad ta[NP], tb[NP], x[NP], y[NP];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) { ta[c] = tq(L.NB2, c); tb[c] = tq(L.D1, c); x[c] = ldq(G + gq(c)); y[c] = ldq(H + gq(c)); }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul_add(ta[c].v[k], x[c].v[k], F::tmul(tb[c].v[k], y[c].v[k]));
+                        stq(G + gq(c), x[c]);
+                    }
+                }
+                __syncthreads();
+                lds_extend_core<F>(G, nh, le, L, 1);
+                Quad uq[NP], vq[NP];
+                {
+                    Quad ta[NP], tb[NP], x[NP], y[NP];
+#pragma unroll
+                    for (int c = 0; c < NP; ++c) { ta[c] = tq(L.w[0], c); tb[c] = tq(L.xie, c); x[c] = ldq(G + gq(c)); y[c] = evenq(c); }
+#pragma unroll
+                    for (int c = 0; c < NP; ++c)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { uq[c].v[k] = F::tmul(ta[c].v[k], x[c].v[k]); vq[c].v[k] = F::tmul(tb[c].v[k], F::sub(y[c].v[k], uq[c].v[k])); }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NP; ++c) {
+                    const uint32_t g = gq(c), i = g & (e - 1), bb = (g >> le) << l;
+                    stq(cur + bb + i, uq[c]); stq(cur + bb + e + i, vq[c]);
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::tmul(L.A1[g & (e - 1)], cur[2 * g]);
         __syncthreads();
         lds_extend_core<F>(G, nh, le, L, 0);
@@ -599,6 +1167,19 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
             cur[bb + i] = u[c]; cur[bb + e + i] = v[c];
         }
         __syncthreads();
+    }
+    if constexpr (kQuad) {
+        if (qio) {
+            constexpr int NQ = (int)(T / (4 * kBlockLds));
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * kBlockLds));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q.v[k] = F::canon(q.v[k]);
+                stq(dst + base + 4u * (tid + (uint32_t)c * kBlockLds), q);
+            }
+            return;
+        }
     }
     for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
 }

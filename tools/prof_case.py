@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One hot-path case, nothing else, for rocprofv3: builds the tree, then runs `reps` calls of one operation on
+device-resident data.  tools/prof_case.sh wraps it with kernel-trace and PMC passes.
+usage: prof_case.py FIELD LOG_N OP [REPS]     OP = enter | exit | extend | both"""
+import sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ecfft_amd
+from bench import synth
+
+field, log_n, op = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+n = 1 << log_n
+F = ecfft_amd.FIELDS[field]
+tree = F.build_fftree(2 * n if op == "extend" else n)
+h = synth(field, n, 7)
+x = torch.from_numpy(h.view(np.int64) if field == "secp256k1" else h.view(np.int32)).cuda()
+torch.cuda.synchronize()
+for _ in range(reps):
+    if op == "enter":
+        y = tree.enter(x)
+    elif op == "exit":
+        y = tree.exit(x)
+    elif op == "extend":
+        y = tree.extend(x, ecfft_amd.Moiety.S1)
+    else:
+        y = tree.exit(tree.enter(x))
+    torch.cuda.synchronize()
+print("done", field, log_n, op, reps)

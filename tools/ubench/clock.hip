@@ -9,9 +9,10 @@
 #include <cstdio>
 #include <cstdint>
 #include "../../ecfft_amd/csrc/field_secp256k1.h"
+#include "../../ecfft_amd/csrc/field_m31.h"
 using namespace ecfft;
 
-constexpr int ITER = 2048;
+constexpr int ITER = 32768;   // long kernels (several ms): launch ramp and block stagger are negligible
 struct Stamp { unsigned long long cyc, wall; };
 
 #define KERNEL_BODY(NAME, DECL, OPS, FOLD)                                                         \
@@ -56,6 +57,25 @@ __global__ __launch_bounds__(256) void k_tmul_chain(uint32_t* out, Stamp* st, ui
     if (threadIdx.x == 0) { st[blockIdx.x].cyc = c_1 - c_0; st[blockIdx.x].wall = w_1 - w_0; }
 }
 
+// M31 table multiply (7 instructions: v_mad_u64_u32, v_and, v_alignbit, v_add, v_and, v_lshrrev, v_add), K independent
+// chains per lane: the butterfly kernels' multiply with and without instruction-level parallelism inside a wave
+template <int K>
+__global__ __launch_bounds__(256) void k_m31_chain(uint32_t* out, Stamp* st, uint32_t seed) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256 + seed;
+    uint32_t x[K], c[K], T[K];
+    for (int k = 0; k < K; ++k) { x[k] = (t * (2654435761u + k)) & 0x7fffffffu; c[k] = (t + k) & 0x7fffffffu; T[k] = (t * 40503u + k * 977u) & 0x3fffffffu; }
+    unsigned long long c_0 = __builtin_amdgcn_s_memtime(), w_0 = wall_clock64();
+#pragma unroll 1
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) x[k] = M31::tmul_add(T[k], x[k], c[k]);
+    }
+    unsigned long long c_1 = __builtin_amdgcn_s_memtime(), w_1 = wall_clock64();
+    uint32_t f = 0; for (int k = 0; k < K; ++k) f ^= x[k];
+    out[threadIdx.x + blockIdx.x * 256] = f;
+    if (threadIdx.x == 0) { st[blockIdx.x].cyc = c_1 - c_0; st[blockIdx.x].wall = w_1 - w_0; }
+}
+
 template <class K>
 void run(const char* name, K kern, uint32_t* d_out, Stamp* d_st, double ops_per_iter, int iters) {
     for (int wps = 1; wps <= 8; wps *= 2) {
@@ -89,5 +109,9 @@ int main() {
     run("v_mad_u64_u32", k_mad_u64_u32, d_out, d_st, 8, ITER);
     run("mad_u64+addc", k_mad_addc, d_out, d_st, 16, ITER);
     run("tmul_add (169 inst)", k_tmul_chain, d_out, d_st, 169, ITER / 8);
+    run("m31 tmul_add x1 (7)", k_m31_chain<1>, d_out, d_st, 7, ITER);
+    run("m31 tmul_add x2 (7)", k_m31_chain<2>, d_out, d_st, 14, ITER);
+    run("m31 tmul_add x4 (7)", k_m31_chain<4>, d_out, d_st, 28, ITER);
+    run("m31 tmul_add x8 (7)", k_m31_chain<8>, d_out, d_st, 56, ITER);
     return 0;
 }
