@@ -296,10 +296,23 @@ def main():
         dist.destroy_process_group()
 
 
+def _make_comm(D, dist, world):
+    """RCCL communicator (one rank per GPU); ECFFT_BENCH_BACKEND=gloo -> host-staged callback transport (functional test only)"""
+    if os.environ.get("ECFFT_BENCH_BACKEND", "nccl") == "nccl":
+        return D.Comm.rccl()
+    return D.Comm.callback()
+
+
+def _split_report(comm, steps):
+    st = comm.stats()
+    return {"comm_ms_per_step": st["comm_ms"] / max(steps, 1), "exchanges_per_step": st["exchanges"] / max(steps, 1),
+            "bytes_sent_per_step_per_rank": st["bytes_sent"] / max(steps, 1)}
+
+
 def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda"):
     """BASELINE configs[3]: one EXTEND of e = 2^log_n evaluations (tree T_2e) with the evaluation domain split over the
-    ranks: block-distributed input, four RCCL all-to-alls (block<->cyclic) around the top log2(P) stages
-    (ecfft_amd/distributed.py).  Strong scaling: total work is fixed.  Checked by S0->S1->S0 round trip (identity)."""
+    ranks: block-distributed input, four grouped ncclSend/ncclRecv exchanges (block<->cyclic) around the top log2(P) stages,
+    all below the C ABI (ecfft_extend_sharded).  Strong scaling: total work is fixed.  Checked by S0->S1->S0 round trip."""
     from ecfft_amd import distributed as D
     e = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
@@ -307,11 +320,10 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     c = e // world
     host = synth(args.field, e, 0x5EED0004)[rank * c:(rank + 1) * c]          # this rank's block of the same global vector
     x = torch.from_numpy(host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).cuda()
+    comm = _make_comm(D, dist, world)
 
     def run(v, moiety):
-        if world == 1:
-            return tree.extend(v, moiety)
-        return D.extend_sharded(D.HipOps(tree), v, e, moiety)
+        return tree.extend_sharded(comm, v, e, moiety)
 
     def barrier():
         torch.cuda.synchronize()
@@ -329,6 +341,16 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     elapsed = time.perf_counter() - t0
     back = run(y, ecfft_amd.Moiety.S0)
     ok = bool(torch.equal(back, x))
+    # second pass with per-exchange events: communication vs compute per step
+    comm.stats(True)
+    barrier(); t1 = time.perf_counter()
+    for _ in range(args.steps):
+        y = run(x, ecfft_amd.Moiety.S1)
+    barrier(); inst = time.perf_counter() - t1
+    phases = _split_report(comm, args.steps)
+    phases["instrumented_ms_per_step"] = inst * 1e3 / max(args.steps, 1)
+    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"]
+    comm.stats(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
         fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
@@ -339,8 +361,8 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
                           "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
                           "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1} (BASELINE.json configs[3])", "e": e,
-                                     "parallelism": f"evaluation domain block-split over {world} GPU(s), 4 all_to_all_single per EXTEND" if world > 1 else "single GPU"},
-                          "round_trip_ok": ok}))
+                                     "parallelism": f"evaluation domain block-split over {world} GPU(s): ecfft_extend_sharded, 4 grouped ncclSend/ncclRecv exchanges per EXTEND"},
+                          "phases": phases, "round_trip_ok": ok}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 
@@ -356,15 +378,11 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     c = n // world
     host = synth(args.field, n, 0x5EED0005)[rank * c:(rank + 1) * c]
     x = torch.from_numpy((host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).reshape(c, -1).copy()).cuda()
-    ops = D.HipOps(tree)
-    groups = D.make_groups() if world > 1 else {}
+    comm = _make_comm(D, dist, world)
 
     def step():
-        if world == 1:
-            ev = tree.enter(x)
-            return tree.exit(ev)
-        ev = D.enter_sharded(ops, x, n, groups)
-        return D.exit_sharded(ops, ev, n, groups)
+        ev = tree.enter_sharded(comm, x, n)
+        return tree.exit_sharded(comm, ev, n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -381,6 +399,15 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     barrier()
     elapsed = time.perf_counter() - t0
     ok = bool(torch.equal(back.reshape(x.shape), x))
+    comm.stats(True)
+    barrier(); t1 = time.perf_counter()
+    for _ in range(args.steps):
+        back = step()
+    barrier(); inst = time.perf_counter() - t1
+    phases = _split_report(comm, args.steps)
+    phases["instrumented_ms_per_step"] = inst * 1e3 / max(args.steps, 1)
+    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"]
+    comm.stats(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
         fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
@@ -391,8 +418,8 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
                           "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
                           "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT, one transform", "n": n,
-                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s); levels above n/P use split EXTENDs and one all_to_all_single per level" if world > 1 else "single GPU"},
-                          "round_trip_ok": ok}))
+                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s): ecfft_enter_sharded / ecfft_exit_sharded; levels above n/P use split EXTENDs and one re-blocking exchange per level"},
+                          "phases": phases, "round_trip_ok": ok}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

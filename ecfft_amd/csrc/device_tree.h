@@ -20,6 +20,7 @@
 #include <new>
 #include "kernels.h"
 #include "host_curve.h"
+#include "transport.h"
 
 namespace ecfft {
 
@@ -246,9 +247,10 @@ public:
                 return false;
             }
             // load side
-            if (first) { d = io; } else { d = IoDesc<F>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
+            if (first) { d = io; d.st_tr_logp = 0; } else { d = IoDesc<F>{}; d.src = plain_src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr; }
             // store side
-            if (last) { d.dst = io.dst; d.st_mode = io.st_mode; d.st_a = io.st_a; d.st_b = io.st_b; d.aux = io.aux; d.aux_stride = io.aux_stride; d.aux_off = io.aux_off; d.aux_out = io.aux_out; }
+            if (last) { d.dst = io.dst; d.st_mode = io.st_mode; d.st_a = io.st_a; d.st_b = io.st_b; d.aux = io.aux; d.aux_stride = io.aux_stride; d.aux_off = io.aux_off; d.aux_out = io.aux_out;
+                        d.st_tr_logp = io.st_tr_logp; d.tr_chunk = io.tr_chunk; }
             else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
             double extra = (first ? extra_first : 0.0) + (last ? extra_last : 0.0);
             const Pass& P = passes[pi];
@@ -341,6 +343,146 @@ public:
     void extend_local_block(E* buf, size_t e, int target, unsigned log_p, hipStream_t s) const {
         unsigned log_m = ilog2(e) + 1;
         extend_core(log_m, io_plain(buf, buf), buf, e >> log_p, 1 - target, s, 0.0, 0.0, log_p);
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // ONE transform split over the ranks of a Transport (one process per GPU).
+    // Everything below the exchange calls is the single-GPU kernels; the block <-> cyclic re-distributions cost no pass of
+    // their own: the pack / unpack index maps ride on the 1/W and W scalings that an EXTEND needs anyway and on the
+    // load / store operators (IoDesc::ld_tr_logp / st_tr_logp) of the block-local fused passes.
+    // ------------------------------------------------------------------------------------------
+    // equal pieces of `piece` elements to / from every rank of the group [gbase, gbase + P)
+    bool exchange_group(Transport& tr, int gbase, size_t P, E* from, E* to, size_t piece, hipStream_t s) const {
+        P2P snd[64], rcv[64];
+        if (P > 64) return false;
+        for (size_t q = 0; q < P; ++q) { snd[q] = {gbase + (int)q, from + q * piece, piece * sizeof(E)}; rcv[q] = {gbase + (int)q, to + q * piece, piece * sizeof(E)}; }
+        return tr.exchange(snd, (int)P, rcv, (int)P, s);
+    }
+    // FFTree::extend (src/fftree.rs:123-126) of ONE vector of e evaluations held block-distributed by the P = 2^log_p ranks
+    // [gbase, gbase + P) of `tr`: rank gbase + r holds positions [r*c, (r+1)*c), c = e/P.  in / out: this rank's shard (may
+    // alias).  A, B: scratch of c elements each.  Stage k pairs (i, i + e >> (k+1)): stages k >= log_p are local in the block
+    // distribution, stages k < log_p in the cyclic one (position j on rank j mod P).
+    bool extend_split(Transport& tr, int gbase, unsigned log_p, const E* in, E* out, size_t e, int target, hipStream_t s, E* A, E* B) const {
+        const unsigned log_m = ilog2(e) + 1;
+        const Tree& T = trees_[log_m];
+        const size_t P = (size_t)1 << log_p, c = e >> log_p, cp = c >> log_p, g0 = (size_t)(tr.rank - gbase) * c;
+        const unsigned r = (unsigned)(tr.rank - gbase);
+        const int src = 1 - target;
+        if (c < P || c < 2) return false;
+        {   // 1/W_src scaling + pack for block -> cyclic: element i goes to rank i mod P, slot i / P
+            const TE* wi = T.winv[src]; const unsigned lp = log_p;
+            foreach_n(s, c, [=] __device__(size_t i) { A[(i & (P - 1)) * cp + (i >> lp)] = F::canon(F::tmul(wi[g0 + i], in[i])); });
+        }
+        if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;          // B = cyclic shard, ascending local index
+        const size_t npairs = c / 2;
+        for (unsigned k = 0; k < log_p; ++k) {                                 // cyclic shard: top decompose stages, table stride P / offset r
+            size_t h = e >> (k + 1), off = e - 2 * h;
+            ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                         B, T.np0[src] + off, T.dinv[src] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
+        }
+        if (!exchange_group(tr, gbase, P, B, A, cp, s)) return false;          // A = the P chunks of the block shard, source major
+        {   // block shard: every stage k >= log_p, fused passes; unpack on the first load, pack on the last store
+            IoDesc<F> io = io_plain(A, B);
+            io.ld_tr_logp = log_p; io.st_tr_logp = log_p; io.tr_chunk = cp;
+            extend_core(log_m, io, out, c, src, s, 0.0, 0.0, log_p);
+        }
+        if (!exchange_group(tr, gbase, P, B, A, cp, s)) return false;          // A = cyclic shard
+        for (unsigned k = log_p; k-- > 0;) {
+            size_t h = e >> (k + 1), off = e - 2 * h;
+            ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                         A, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
+        }
+        if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;          // B = chunks of the block shard
+        {   // unpack + W_target scaling
+            const TE* w = T.w[target]; const unsigned lp = log_p;
+            foreach_n(s, c, [=] __device__(size_t i) { out[i] = F::canon(F::tmul(w[g0 + i], B[(i & (P - 1)) * cp + (i >> lp)])); });
+        }
+        return hipGetLastError() == hipSuccess;
+    }
+    bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s) {
+        const size_t P = (size_t)tr.world, c = e / P;
+        if (P & (P - 1)) return false;
+        E* A = temp(c); E* B = temp(c);
+        bool ok = extend_split(tr, 0, ilog2(P), in, out, e, target, s, A, B);
+        temps_done();
+        return ok;
+    }
+    // FFTree::enter of n coefficients block-distributed over all ranks of `tr` (rank r holds [r*c, (r+1)*c), c = n/P).
+    // Levels m <= c are the rank-local ENTER of the chunk; level m = c*Q (Q = 2, 4, .. P) works inside groups of Q consecutive
+    // ranks: a split EXTEND over the half-group that holds u0 (or v0), then ONE exchange re-blocks [u0 | v0 | u1 | v1] so that
+    // every rank owns the pairs whose interleaved outputs (src/fftree.rs:155-159) form its block of the level's result.
+    bool api_enter_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
+        const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
+        if ((P & (P - 1)) || c < 2 * P) return false;
+        E* cur = temp(c); E* ext = temp(c); E* R = temp(2 * c); E* A = temp(c); E* B = temp(c);
+        bool ok = enter(in, cur, c, 1, s);
+        for (size_t Q = 2; ok && Q <= P; Q *= 2) {
+            const size_t half = Q / 2, m = c * Q, e = m / 2;
+            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, a2 = a % (int)half, ap = a / 2, b = a % 2;
+            if (half == 1) ok = extend(cur, ext, e, 1, 1, s);
+            else ok = extend_split(tr, base + (a / (int)half) * (int)half, ilog2(half), cur, ext, e, 1, s, A, B);
+            if (!ok) break;
+            P2P snd[4] = {{base + 2 * a2, cur, hc * sizeof(E)}, {base + 2 * a2, ext, hc * sizeof(E)},
+                          {base + 2 * a2 + 1, cur + hc, hc * sizeof(E)}, {base + 2 * a2 + 1, ext + hc, hc * sizeof(E)}};
+            P2P rcv[4] = {{base + ap, R, hc * sizeof(E)}, {base + ap, R + hc, hc * sizeof(E)},
+                          {base + (int)half + ap, R + 2 * hc, hc * sizeof(E)}, {base + (int)half + ap, R + 3 * hc, hc * sizeof(E)}};
+            ok = tr.exchange(snd, 4, rcv, 4, s);
+            const E* xnn = trees_[ilog2(m)].xnn; const size_t i0 = (size_t)ap * c + (size_t)b * hc;
+            const E *u0 = R, *u1 = R + hc, *v0 = R + 2 * hc, *v1 = R + 3 * hc;
+            foreach_n(s, hc, [=] __device__(size_t j) {
+                cur[2 * j] = F::mul_add(xnn[2 * (i0 + j)], v0[j], u0[j]);             // :157
+                cur[2 * j + 1] = F::mul_add(xnn[2 * (i0 + j) + 1], v1[j], u1[j]);     // :158
+            });
+        }
+        if (ok) ok = hipMemcpyAsync(out, cur, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess && hipGetLastError() == hipSuccess;
+        temps_done();
+        return ok;
+    }
+    // FFTree::exit of n evaluations block-distributed over all ranks.  Level m = c*Q runs inside groups of Q ranks with every
+    // length-m/2 vector spread over the whole group (c/2 entries per rank: the even / odd de-interleave is local); REDC and the
+    // pointwise steps are src/fftree.rs:206-219, 232-259, 277-281 restricted to the rank's index range; one exchange per level
+    // re-blocks [u0 | v0].  Levels m <= c: the rank-local EXIT.
+    bool api_exit_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
+        const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
+        if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
+        E* cur = temp(c); E* e0 = temp(hc); E* e1 = temp(hc); E* t0 = temp(hc); E* h0 = temp(hc); E* h1 = temp(hc); E* A = temp(hc); E* B = temp(hc);
+        bool ok = hipMemcpyAsync(cur, in, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
+        for (size_t Q = P; ok && Q >= 2; Q /= 2) {
+            const size_t half = Q / 2, m = c * Q, e = m / 2;
+            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a < (int)half ? a : a - (int)half;
+            const unsigned lq = ilog2(Q);
+            const Tree& T = trees_[ilog2(m)];
+            const E *xnn = T.xnn, *xi = T.xnn_inv, *zi = T.z0_inv_s1, *cc = T.z0z0;
+            const size_t i0 = (size_t)a * hc;
+            foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = cur[2 * j]; e1[j] = cur[2 * j + 1]; });
+            // redc_impl with a = xnn_s, moiety S0 (:232-259): (x0, x1) -> (h0, h1)
+            auto redc = [&](const E* x0, const E* x1) -> bool {
+                foreach_n(s, hc, [=] __device__(size_t j) { t0[j] = F::mul(xi[2 * (i0 + j)], x0[j]); });                               // :238
+                if (!extend_split(tr, base, lq, t0, t0, e, 1, s, A, B)) return false;                                                 // g1 (:239-245)
+                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(zi[i0 + j], F::sub(x1[j], F::mul(xnn[2 * (i0 + j) + 1], t0[j]))); });   // :253-255
+                return extend_split(tr, base, lq, h1, h0, e, 0, s, A, B);                                                             // :256
+            };
+            ok = redc(e0, e1);                                                                                                        // modular_reduce_impl (:277-281)
+            if (!ok) break;
+            foreach_n(s, hc, [=] __device__(size_t j) { h0[j] = F::mul(cc[2 * (i0 + j)], h0[j]); h1[j] = F::mul(cc[2 * (i0 + j) + 1], h1[j]); });
+            {   // second REDC reads (h0, h1) and overwrites them: stage its inputs
+                E* x0 = e1;                                   // e1 is free after the first REDC
+                foreach_n(s, hc, [=] __device__(size_t j) { x0[j] = h0[j]; });
+                E* x1 = cur;                                  // cur's first half is free until the re-blocking below
+                foreach_n(s, hc, [=] __device__(size_t j) { x1[j] = h1[j]; });
+                ok = redc(x0, x1);
+            }
+            if (!ok) break;
+            // u0 = h0; v0 = (e0 - u0) * xnn_inv[even]  (:215-219), kept in h1
+            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[2 * (i0 + j)], F::sub(e0[j], h0[j])); });
+            P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
+            P2P rcv[2] = {{base + 2 * ap, cur, hc * sizeof(E)}, {base + 2 * ap + 1, cur + hc, hc * sizeof(E)}};
+            ok = tr.exchange(snd, 2, rcv, 2, s);
+        }
+        if (ok) ok = exit(cur, out, c, 1, s);
+        ok = ok && hipGetLastError() == hipSuccess;
+        temps_done();
+        return ok;
     }
 
     // FFTree::enter (src/fftree.rs:164-167): n coefficients -> n evaluations on the leaves of T_n.

@@ -386,6 +386,35 @@ int run_mul_ceiling(int device, int waves_per_simd, double* mul_per_s) {
     return ECFFT_OK;
 }
 
+namespace {
+template <class F>
+int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const void* in, void* out, size_t len, int moiety, void* stream) {
+    using E = typename F::elem;
+    if (!in || !out || !comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    if (!is_pow2(len)) return ECFFT_ERR_NOT_POW2;
+    Transport& tr = *comm->t;
+    const size_t P = (size_t)tr.world;
+    if (!is_pow2(P) || P > 64) return ECFFT_ERR_BAD_ARG;
+    size_t need_tree = (op == OP_EXTEND) ? len * 2 : len;
+    if (need_tree > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
+    if (op == OP_EXTEND && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
+    if (len / P < 2 * P) return ECFFT_ERR_BAD_ARG;                       // every rank needs at least 2P elements
+    hipStream_t s = (hipStream_t)stream;
+    DeviceGuard dev(c->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    std::lock_guard<std::mutex> guard(ch.lock());
+    OpScope scope(c, s);
+    if (!scope.ok) return ECFFT_ERR_HIP;
+    bool ok = false;
+    switch (op) {
+        case OP_EXTEND: ok = ch.api_extend_split(tr, (const E*)in, (E*)out, len, moiety, s); break;
+        case OP_ENTER: ok = ch.api_enter_split(tr, (const E*)in, (E*)out, len, s); break;
+        case OP_EXIT: ok = ch.api_exit_split(tr, (const E*)in, (E*)out, len, s); break;
+    }
+    return ok && hipGetLastError() == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+}  // namespace
+
 extern "C" {
 
 size_t ecfft_elem_size(int field) { return field == ECFFT_FIELD_SECP256K1 ? 32 : (field == ECFFT_FIELD_M31 ? 4 : 0); }
@@ -564,6 +593,82 @@ int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* str
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree); });
 }
 
+// ---- one transform split over several GPUs -------------------------------------------------------------------------
+int ecfft_comm_get_unique_id(void* id_out) {
+    if (!id_out) return ECFFT_ERR_BAD_ARG;
+    RcclApi& api = RcclApi::get();
+    if (!api.ok()) return ECFFT_ERR_HIP;
+    RcclApi::UniqueId id;
+    if (api.GetUniqueId(&id) != 0) return ECFFT_ERR_HIP;
+    memcpy(id_out, id.internal, ECFFT_COMM_ID_BYTES);
+    return ECFFT_OK;
+}
+int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    std::unique_ptr<RcclTransport> t(new (std::nothrow) RcclTransport());
+    if (!t || !t->init(id, world, rank, device)) return ECFFT_ERR_HIP;
+    ecfft_comm* c = new (std::nothrow) ecfft_comm();
+    if (!c) return ECFFT_ERR_HIP;
+    c->t = t.release();
+    *out = c;
+    return ECFFT_OK;
+}
+int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn fn, void* user, ecfft_comm** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!fn || world < 1 || rank < 0 || rank >= world) return ECFFT_ERR_BAD_ARG;
+    ecfft_comm* c = new (std::nothrow) ecfft_comm();
+    if (!c) return ECFFT_ERR_HIP;
+    c->t = new (std::nothrow) CallbackTransport(world, rank, device, fn, user);
+    if (!c->t) { delete c; return ECFFT_ERR_HIP; }
+    *out = c;
+    return ECFFT_OK;
+}
+void ecfft_comm_destroy(ecfft_comm* comm) {
+    if (!comm) return;
+    DeviceGuard dev(comm->t ? comm->t->device : 0);
+    delete comm;
+}
+int ecfft_comm_rank(const ecfft_comm* comm) { return comm && comm->t ? comm->t->rank : -1; }
+int ecfft_comm_world(const ecfft_comm* comm) { return comm && comm->t ? comm->t->world : 0; }
+int ecfft_comm_stats_enable(ecfft_comm* comm, int on) {
+    if (!comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(comm->t->device);
+    if (!dev.ok || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    comm->t->stats_enable(on != 0);
+    return ECFFT_OK;
+}
+int ecfft_comm_stats_read(ecfft_comm* comm, double* comm_ms, double* exchanges, double* bytes_sent) {
+    if (!comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(comm->t->device);
+    if (!dev.ok || hipDeviceSynchronize() != hipSuccess) return ECFFT_ERR_HIP;
+    comm->t->stats_read(comm_ms, exchanges, bytes_sent);
+    comm->t->stats_reset();
+    return ECFFT_OK;
+}
+
+
+int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXTEND, in, out, e, moiety, stream)
+                                                                    : run_sharded(ctx, *ctx->m31, comm, OP_EXTEND, in, out, e, moiety, stream); });
+}
+int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_ENTER, coeffs, evals, n, 0, stream)
+                                                                    : run_sharded(ctx, *ctx->m31, comm, OP_ENTER, coeffs, evals, n, 0, stream); });
+}
+int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXIT, evals, coeffs, n, 0, stream)
+                                                                    : run_sharded(ctx, *ctx->m31, comm, OP_EXIT, evals, coeffs, n, 0, stream); });
+}
+
 int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
                     size_t t_stride, int mode, int mem, void* stream) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
@@ -629,6 +734,12 @@ int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);
     return ECFFT_ERR_BAD_ARG;
+}
+
+int ecfft_device_copy(void* dst, const void* src, size_t bytes, int kind) {
+    hipMemcpyKind k = kind == 0 ? hipMemcpyDeviceToHost : (kind == 1 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+    if (!dst || !src || kind < 0 || kind > 2) return ECFFT_ERR_BAD_ARG;
+    return hipMemcpy(dst, src, bytes, k) == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
 int ecfft_device_info(int device, char* buf, size_t cap) {

@@ -77,7 +77,9 @@ struct IoDesc {
     using E = typename F::elem;
     using TE = typename F::telem;
     // load:  x = [ld_tbl[i] *] src[src_stride*pos + src_off]
-    const E* src; uint32_t src_stride, src_off; int ld_mode; const TE* ld_tbl;
+    //        ld_tr_logp > 0: src holds the P = 2^ld_tr_logp chunks of an all-to-all, source-rank major, and position pos of the
+    //        block shard is element pos / P of chunk pos mod P:  src[(pos mod P)*tr_chunk + pos / P]   (split EXTEND)
+    const E* src; uint32_t src_stride, src_off; int ld_mode; const TE* ld_tbl; uint32_t ld_tr_logp, st_tr_logp; size_t tr_chunk;
     // store: ST_PLAIN  dst[pos] = x
     //        ST_SCALE  dst[pos] = st_a[i]*x
     //        ST_AXPBY  r = st_a[i]*x + st_b[i]*aux[aux_stride*pos + aux_off]; dst[pos] = r; aux_out[pos] = r (if set)
@@ -90,7 +92,8 @@ struct IoDesc {
 
 template <class F>
 __device__ __forceinline__ typename F::elem io_load(const IoDesc<F>& io, size_t pos, size_t emask) {
-    typename F::elem v = io.src[(size_t)io.src_stride * pos + io.src_off];
+    typename F::elem v = io.ld_tr_logp ? io.src[(pos & (((size_t)1 << io.ld_tr_logp) - 1)) * io.tr_chunk + (pos >> io.ld_tr_logp)]
+                                       : io.src[(size_t)io.src_stride * pos + io.src_off];
     if (io.ld_mode == LD_SCALE) v = F::tmul(io.ld_tbl[pos & emask], v);
     return v;
 }
@@ -99,7 +102,10 @@ __device__ __forceinline__ void io_store(const IoDesc<F>& io, size_t pos, uint32
     using E = typename F::elem;
     const size_t emask = ((size_t)1 << log_e) - 1, i = pos & emask;
     switch (io.st_mode) {
-        case ST_PLAIN: io.dst[pos] = F::canon(x); break;
+        case ST_PLAIN:   // st_tr_logp > 0: the mirror image of the transposed load — scatter into the send chunks of an all-to-all
+            if (io.st_tr_logp) io.dst[(pos & (((size_t)1 << io.st_tr_logp) - 1)) * io.tr_chunk + (pos >> io.st_tr_logp)] = F::canon(x);
+            else io.dst[pos] = F::canon(x);
+            break;
         case ST_SCALE: io.dst[pos] = F::canon(F::tmul(io.st_a[i], x)); break;
         case ST_AXPBY: {
             E r = F::canon(F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off])));
@@ -154,7 +160,7 @@ template <class F>
 __device__ __forceinline__ bool vio_ok(const IoDesc<F>& io, uint32_t log_e) {
     if constexpr (sizeof(typename F::elem) != 4) return false;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    bool ok = log_e >= 2 && al(io.src) && al(io.dst) && ((io.src_stride == 1 && io.src_off == 0) || (io.src_stride == 2 && io.src_off < 2));
+    bool ok = log_e >= 2 && io.ld_tr_logp == 0 && io.st_tr_logp == 0 && al(io.src) && al(io.dst) && ((io.src_stride == 1 && io.src_off == 0) || (io.src_stride == 2 && io.src_off < 2));
     if (io.ld_mode == LD_SCALE) ok = ok && al(io.ld_tbl);
     if (io.st_mode == ST_SCALE || io.st_mode == ST_AXPBY || io.st_mode == ST_EXIT_SPLIT) ok = ok && al(io.st_a);
     if (io.st_mode == ST_AXPBY || io.st_mode == ST_EXIT_SPLIT) ok = ok && al(io.st_b) && al(io.aux) && ((io.aux_stride == 1 && io.aux_off == 0) || (io.aux_stride == 2 && io.aux_off < 2));

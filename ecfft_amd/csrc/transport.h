@@ -1,0 +1,143 @@
+// Inter-GPU transport of the sharded transforms (one process per GPU).  The data path needs ONE primitive: a set of
+// point-to-point sends and receives of device buffers that progress together (an all-to-all inside a group of ranks is the
+// special case "one equal piece to and from every member").
+//
+//   RcclTransport      RCCL (librccl.so, loaded at run time so that single-GPU users carry no dependency) — grouped
+//                      ncclSend / ncclRecv on the caller's HIP stream: one message per peer = one per xGMI link.
+//   CallbackTransport  the host application moves the buffers (tests: torch.distributed/gloo staged through host memory,
+//                      several ranks sharing one GPU — RCCL refuses two ranks on one device).
+//
+// Per-exchange HIP events (optional) split a sharded transform's time into communication and compute for bench.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/ecfft_hip.h"
+
+namespace ecfft {
+
+struct P2P { int peer; void* ptr; size_t bytes; };
+
+class Transport {
+public:
+    virtual ~Transport() { for (hipEvent_t e : ev_) (void)hipEventDestroy(e); }
+    int rank = 0, world = 1, device = 0;
+    // every send and receive of the call progresses together (ncclGroupStart / ncclGroupEnd semantics); messages between one
+    // pair of ranks match in the order given; buffers are device memory; the work is enqueued on `s`
+    bool exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (stats_on_) { a = next_event(); b = next_event(); (void)hipEventRecord(a, s); }
+        bool ok = do_exchange(sends, ns, recvs, nr, s);
+        if (stats_on_) { (void)hipEventRecord(b, s); pairs_.push_back({a, b}); }
+        ++calls_;
+        for (int i = 0; i < ns; ++i) bytes_ += (double)sends[i].bytes;
+        return ok;
+    }
+    void stats_enable(bool on) { stats_on_ = on; stats_reset(); }
+    void stats_reset() { used_ = 0; pairs_.clear(); calls_ = 0; bytes_ = 0; }
+    // caller has synchronised the stream(s)
+    void stats_read(double* comm_ms, double* calls, double* bytes) {
+        double ms = 0;
+        for (auto& p : pairs_) { float t = 0; if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) ms += t; }
+        if (comm_ms) *comm_ms = ms;
+        if (calls) *calls = (double)calls_;
+        if (bytes) *bytes = bytes_;
+    }
+protected:
+    virtual bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) = 0;
+private:
+    hipEvent_t next_event() { if (used_ == ev_.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_.push_back(e); } return ev_[used_++]; }
+    struct Pair { hipEvent_t a, b; };
+    std::vector<hipEvent_t> ev_; size_t used_ = 0; std::vector<Pair> pairs_;
+    bool stats_on_ = false; uint64_t calls_ = 0; double bytes_ = 0;
+};
+
+// ---- RCCL, bound at run time -------------------------------------------------------------------------------------------
+struct RcclApi {
+    struct UniqueId { char internal[128]; };             // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+    typedef void* Comm;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* handle = nullptr;
+    bool ok() const { return handle && GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd; }
+
+    static RcclApi& get() {
+        static RcclApi api = load();
+        return api;
+    }
+private:
+    static RcclApi load() {
+        RcclApi a;
+        // reuse the copy that is already mapped (PyTorch-ROCm bundles its own librccl and has it loaded), else the system one
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (a.handle) break; }
+        if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) break; }
+        if (!a.handle) { fprintf(stderr, "ecfft: librccl.so not found (%s)\n", dlerror()); return a; }
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+        a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
+        a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+        return a;
+    }
+};
+
+class RcclTransport : public Transport {
+public:
+    ~RcclTransport() override { if (comm_) (void)RcclApi::get().CommDestroy(comm_); }
+    bool init(const void* id128, int world_, int rank_, int device_) {
+        RcclApi& api = RcclApi::get();
+        if (!api.ok()) return false;
+        RcclApi::UniqueId id; memcpy(id.internal, id128, sizeof(id.internal));
+        world = world_; rank = rank_; device = device_;
+        int rc = api.CommInitRank(&comm_, world, id, rank);
+        if (rc != 0) { fprintf(stderr, "ecfft: ncclCommInitRank failed: %s\n", api.GetErrorString ? api.GetErrorString(rc) : "?"); comm_ = nullptr; return false; }
+        return true;
+    }
+protected:
+    bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
+        RcclApi& api = RcclApi::get();
+        const int kChar = 0;                              // ncclChar / ncclInt8
+        int rc = api.GroupStart();
+        for (int i = 0; i < ns && rc == 0; ++i) rc = api.Send(sends[i].ptr, sends[i].bytes, kChar, sends[i].peer, comm_, s);
+        for (int i = 0; i < nr && rc == 0; ++i) rc = api.Recv(recvs[i].ptr, recvs[i].bytes, kChar, recvs[i].peer, comm_, s);
+        int rc2 = api.GroupEnd();
+        if (rc == 0) rc = rc2;
+        if (rc != 0) fprintf(stderr, "ecfft: RCCL exchange failed: %s\n", api.GetErrorString ? api.GetErrorString(rc) : "?");
+        return rc == 0;
+    }
+private:
+    RcclApi::Comm comm_ = nullptr;
+};
+
+class CallbackTransport : public Transport {
+public:
+    CallbackTransport(int world_, int rank_, int device_, ecfft_exchange_fn fn, void* user) : fn_(fn), user_(user) { world = world_; rank = rank_; device = device_; }
+protected:
+    bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
+        std::vector<int> sp(ns), rp(nr); std::vector<const void*> sptr(ns); std::vector<void*> rptr(nr); std::vector<size_t> sb(ns), rb(nr);
+        for (int i = 0; i < ns; ++i) { sp[i] = sends[i].peer; sptr[i] = sends[i].ptr; sb[i] = sends[i].bytes; }
+        for (int i = 0; i < nr; ++i) { rp[i] = recvs[i].peer; rptr[i] = recvs[i].ptr; rb[i] = recvs[i].bytes; }
+        return fn_(user_, ns, sp.data(), sptr.data(), sb.data(), nr, rp.data(), rptr.data(), rb.data(), (void*)s) == 0;
+    }
+private:
+    ecfft_exchange_fn fn_; void* user_;
+};
+
+}  // namespace ecfft
+
+struct ecfft_comm {
+    ecfft::Transport* t = nullptr;
+    ~ecfft_comm() { delete t; }
+};

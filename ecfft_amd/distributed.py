@@ -1,6 +1,16 @@
-"""One EXTEND split across the P GPUs of a node (BASELINE.json configs[3]).
+"""ONE transform split across the GPUs of a node (BASELINE.json configs[3]).
 
-Block-distributed I/O: rank r holds global positions [r*e/P, (r+1)*e/P) of the length-e vector.
+Production path: the orchestration lives BELOW the C ABI (ecfft_extend_sharded / ecfft_enter_sharded / ecfft_exit_sharded,
+ecfft_amd/csrc/device_tree.h: extend_split, api_enter_split, api_exit_split) and moves data with grouped ncclSend / ncclRecv
+on librccl directly.  This module only
+  * creates the communicator: `Comm.rccl()` (rank 0 makes the RCCL unique id, torch.distributed hands it round) or
+    `Comm.callback()` (the exchanges are done by torch.distributed point-to-point calls staged through host memory: lets
+    several ranks share one GPU in the tests, where RCCL refuses duplicate devices), and
+  * keeps a pure-Python MODEL of the same algorithm (`extend_sharded`, `enter_sharded`, `exit_sharded` below, pluggable local
+    ops) that the CPU test-suite runs over gloo with numpy / oracle local stages: the index maps of the split are tested
+    without a GPU, and the C++ path is tested against the single-GPU transforms on the GPU box.
+
+Index maps.  Block-distributed I/O: rank r holds global positions [r*e/P, (r+1)*e/P) of the length-e vector.
 Butterfly stage k pairs (i, i + e >> (k+1)):
   * in the BLOCK distribution every stage k >= log2 P is local,
   * in the CYCLIC distribution (position j on rank j mod P) every stage k < log2(e) - log2(P) is local,
@@ -9,17 +19,131 @@ so the transform is
           --all-to-all--> block  : all remaining stages, decompose then recombine  (the fused single-GPU kernels)
           --all-to-all--> cyclic : recombine stages logP-1..0 + W scaling
           --all-to-all--> block.
-Each all-to-all (`torch.distributed.all_to_all_single`; backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
-in the CPU tests) sends one equal message per peer — one per point-to-point xGMI link.
+Each all-to-all sends one equal message per peer — one per point-to-point xGMI link.
 
-The local compute is delegated to `ops`, an object with
+The model delegates local compute to `ops`, an object with
     ops.top_cyclic(shard, e, moiety, log_p, rank, recombine)   (in place)
     ops.local_block(shard, e, moiety, log_p)                   (in place)
-In production `ops` is an `ecfft_amd.FFTree` (HIP kernels through the C ABI); the CPU tests plug in a numpy
-implementation built from the reference's own matrices so that the data movement is tested without a GPU.
+(`HipOps`: the C-ABI building blocks on device tensors; the CPU tests plug in a numpy implementation built from the
+reference's own matrices).
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+
+class Comm:
+    """`ecfft_comm` of the C ABI: the inter-GPU transport of the sharded transforms (one process per GPU)."""
+
+    def __init__(self, handle, keep=None):
+        self._h, self._keep = handle, keep
+
+    def __del__(self):
+        try:
+            if self._h:
+                from . import fftree
+                fftree.lib().ecfft_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def rank(self):
+        from . import fftree
+        return fftree.lib().ecfft_comm_rank(self._h)
+
+    @property
+    def world(self):
+        from . import fftree
+        return fftree.lib().ecfft_comm_world(self._h)
+
+    @staticmethod
+    def rccl(device=None, world=None, rank=None):
+        """RCCL communicator over all ranks of the default process group (or a single-rank one when torch.distributed is
+        not initialised): rank 0 creates the unique id, torch.distributed broadcasts it, every rank calls ncclCommInitRank."""
+        from . import fftree
+        L = fftree.lib()
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        device = torch.cuda.current_device() if device is None else device
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            fftree._check(L.ecfft_comm_get_unique_id(buf))
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)
+            buf = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        fftree._check(L.ecfft_comm_init_rank(buf, world, rank, device, ctypes.byref(h)))
+        return Comm(h)
+
+    @staticmethod
+    def callback(device=None):
+        """communicator whose exchanges run over torch.distributed point-to-point calls staged through host memory (any
+        backend; the tests use gloo with several ranks on one GPU)"""
+        from . import fftree
+        import numpy as np
+        L = fftree.lib()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        device = torch.cuda.current_device() if device is None else device
+
+        def exchange(user, ns, sp, sptr, sb, nr, rp, rptr, rb, stream):
+            try:
+                torch.cuda.synchronize()
+                sends, recvs = {}, {}                      # peer -> list of (ptr, bytes), in the order given
+                for i in range(ns):
+                    sends.setdefault(sp[i], []).append((sptr[i], sb[i]))
+                for i in range(nr):
+                    recvs.setdefault(rp[i], []).append((rptr[i], rb[i]))
+                ops, rbufs = [], {}
+                for peer, items in recvs.items():
+                    if peer == rank:
+                        continue
+                    rbufs[peer] = torch.empty(sum(b for _, b in items), dtype=torch.uint8)
+                    ops.append(dist.P2POp(dist.irecv, rbufs[peer], peer))
+                for peer, items in sends.items():
+                    host = np.empty(sum(b for _, b in items), dtype=np.uint8)
+                    off = 0
+                    for ptr, b in items:
+                        if L.ecfft_device_copy(host.ctypes.data + off, ptr, b, 0) != 0:
+                            return 1
+                        off += b
+                    if peer == rank:
+                        rbufs[peer] = torch.from_numpy(host)
+                    else:
+                        ops.append(dist.P2POp(dist.isend, torch.from_numpy(host), peer))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                for peer, items in recvs.items():
+                    host = rbufs[peer].numpy()
+                    off = 0
+                    for ptr, b in items:
+                        if L.ecfft_device_copy(ptr, host.ctypes.data + off, b, 1) != 0:
+                            return 1
+                        off += b
+                return 0
+            except Exception as ex:  # pragma: no cover - surfaced as ECFFT_ERR_HIP by the library
+                print("ecfft exchange callback failed:", ex)
+                return 1
+        cb = fftree.EXCHANGE_FN(exchange)
+        h = ctypes.c_void_p()
+        fftree._check(L.ecfft_comm_init_callback(world, rank, device, cb, None, ctypes.byref(h)))
+        return Comm(h, keep=cb)
+
+    def stats(self, enable=None):
+        """enable=True/False switches per-exchange timing on / off; enable=None reads {comm_ms, exchanges, bytes_sent} and resets"""
+        from . import fftree
+        L = fftree.lib()
+        if enable is not None:
+            fftree._check(L.ecfft_comm_stats_enable(self._h, int(enable)))
+            return None
+        ms, n, b = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        fftree._check(L.ecfft_comm_stats_read(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
+        return {"comm_ms": ms.value, "exchanges": n.value, "bytes_sent": b.value}
 
 
 TBL_XNN_S, TBL_XNN_S_INV, TBL_Z0_INV_S1, TBL_Z0Z0 = 3, 4, 7, 9      # ECFFT_TBL_* ids (include/ecfft_hip.h)
@@ -97,9 +221,7 @@ def extend_sharded(ops, x_block, e, moiety, group=None):
     c = shape[0]
     assert c * world == e and c >= 2 * world, "need e/P elements per rank and at least 2P of them"
     x = x_block.reshape(c, -1)
-    if world == 1:
-        raise ValueError("use FFTree.extend on a single rank")
-    y = block_to_cyclic(x, world, group)
+    y = block_to_cyclic(x, world, group)                  # world == 1: a self all-to-all, log_p = 0 (no cyclic stage)
     ops.top_cyclic(y, e, moiety, log_p, rank, False)
     z = cyclic_to_block(y, world, group)
     ops.local_block(z, e, moiety, log_p)

@@ -28,7 +28,13 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree"]
+           "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
+           "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy"]
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p)
 
 
 class Moiety(enum.IntEnum):
@@ -85,6 +91,18 @@ def lib():
         L.ecfft_modular_reduce.restype, L.ecfft_modular_reduce.argtypes = ci, [vp, vp, vp, vp, vp, sz, ci, vp]
         L.ecfft_vanish.restype, L.ecfft_vanish.argtypes = ci, [vp, vp, vp, sz, ci, vp]
         L.ecfft_degree.restype, L.ecfft_degree.argtypes = ci, [vp, vp, sz, ci, vp, ctypes.POINTER(sz)]
+        L.ecfft_comm_get_unique_id.restype, L.ecfft_comm_get_unique_id.argtypes = ci, [vp]
+        L.ecfft_comm_init_rank.restype, L.ecfft_comm_init_rank.argtypes = ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]
+        L.ecfft_comm_init_callback.restype, L.ecfft_comm_init_callback.argtypes = ci, [ci, ci, ci, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
+        L.ecfft_comm_destroy.restype, L.ecfft_comm_destroy.argtypes = None, [vp]
+        L.ecfft_comm_rank.restype, L.ecfft_comm_rank.argtypes = ci, [vp]
+        L.ecfft_comm_world.restype, L.ecfft_comm_world.argtypes = ci, [vp]
+        L.ecfft_comm_stats_enable.restype, L.ecfft_comm_stats_enable.argtypes = ci, [vp, ci]
+        L.ecfft_comm_stats_read.restype, L.ecfft_comm_stats_read.argtypes = ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
+        L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+        L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+        L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
         L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
         L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
@@ -308,6 +326,25 @@ class FFTree:
     def extend_local_block(self, shard, e, moiety, log_p):
         ptr, mem, stream = self._inplace(shard)
         _check(lib().ecfft_extend_local_block(self._h, ptr, e, int(moiety), log_p, mem, stream))
+
+    # ---- ONE transform split over the GPUs of a communicator (device tensors: this rank's block shard) -------------
+    def _sharded(self, fn, comm, x, length, *extra):
+        import torch
+        assert _is_torch(x) and x.is_cuda and x.is_contiguous(), "sharded transforms take contiguous CUDA tensors"
+        out = torch.empty_like(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(fn(self._h, comm._h, x.data_ptr(), out.data_ptr(), length, *extra, stream))
+        return out
+
+    def extend_sharded(self, comm, x_block, e, moiety):
+        """FFTree::extend of ONE length-e vector held block-distributed over the ranks of `comm` (C++ / RCCL path)"""
+        return self._sharded(lib().ecfft_extend_sharded, comm, x_block, e, int(moiety))
+
+    def enter_sharded(self, comm, x_block, n):
+        return self._sharded(lib().ecfft_enter_sharded, comm, x_block, n)
+
+    def exit_sharded(self, comm, y_block, n):
+        return self._sharded(lib().ecfft_exit_sharded, comm, y_block, n)
 
     # ---- benchmarking aid -------------------------------------------------------------------
     def profile(self, on):

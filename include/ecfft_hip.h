@@ -101,9 +101,8 @@ int ecfft_modular_reduce(ecfft_ctx* ctx, const void* evals, const void* a, const
 int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int mem, void* stream);
 int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree);
 
-/* Building blocks of ONE EXTEND of e evaluations (tree T_{2e}) split over P = 2^log_p GPUs; the
- * orchestration (RCCL all-to-all between the block and the cyclic distribution) lives above the ABI,
- * see ecfft_amd/distributed.py and DESIGN.md section 8.  No reference counterpart (the reference is
+/* Building blocks of ONE EXTEND of e evaluations (tree T_{2e}) split over P = 2^log_p GPUs, for hosts that drive the
+ * exchanges themselves (ecfft_extend_sharded below does the whole thing); see DESIGN.md section 8.  No reference counterpart (the reference is
  * single-process); together they compute exactly FFTree::extend (src/fftree.rs:123-126).
  *   ecfft_extend_top_cyclic : buf = the rank's CYCLIC shard (local j' <-> global j'*P + rank, e/P elements).
  *                             recombine = 0: multiply by 1/W_src, then decompose stages 0..log_p-1;
@@ -113,6 +112,36 @@ int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* str
 int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int recombine,
                             int mem, void* stream);
 int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream);
+
+/* ---- ONE transform split over several GPUs, one process per GPU (no reference counterpart: the reference is single
+ * threaded; together the ranks compute exactly FFTree::extend / enter / exit, src/fftree.rs:123-126, 164-167, 227-230).
+ * The loops being split are the butterfly stage loops src/fftree.rs:83-97 and 104-118: stage k pairs (i, i + e >> (k+1)), so
+ * stages k >= log2 P are local when the vector is BLOCK distributed (rank r holds [r*len/P, (r+1)*len/P)) and stages
+ * k < log2 P are local when it is CYCLIC (position j on rank j mod P); an all-to-all inside the group switches between the
+ * two.  Data moves GPU to GPU through an `ecfft_comm`:
+ *   ecfft_comm_get_unique_id + ecfft_comm_init_rank   RCCL (ncclGetUniqueId / ncclCommInitRank; librccl.so is loaded at run
+ *       time): grouped ncclSend / ncclRecv over xGMI on the caller's stream.  Rank 0 creates the 128-byte id and hands it to
+ *       the other ranks by any means (MPI, TCP, a file, torch.distributed); every context of the job is built for its own GPU.
+ *   ecfft_comm_init_callback   the host moves the device buffers itself (tests: several ranks sharing one GPU over gloo).
+ * Arguments: device pointers only; `in` / `out` = this rank's BLOCK shard (len / world elements, may alias); world = 2^k;
+ * len / world >= 2 * world.  Every rank of the communicator makes the same call with the same len.  Asynchronous on `stream`. */
+typedef struct ecfft_comm ecfft_comm;
+#define ECFFT_COMM_ID_BYTES 128
+/* n sends and n receives of device buffers that must progress together; return 0 on success */
+typedef int (*ecfft_exchange_fn)(void* user, int n_send, const int* send_peer, const void* const* send_ptr, const size_t* send_bytes,
+                                 int n_recv, const int* recv_peer, void* const* recv_ptr, const size_t* recv_bytes, void* stream);
+int ecfft_comm_get_unique_id(void* id_out);                                                      /* ECFFT_COMM_ID_BYTES bytes */
+int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out);
+int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn fn, void* user, ecfft_comm** out);
+void ecfft_comm_destroy(ecfft_comm* comm);
+int ecfft_comm_rank(const ecfft_comm* comm);
+int ecfft_comm_world(const ecfft_comm* comm);
+/* communication time: while enabled every exchange is bracketed by HIP events on its stream; _read synchronises the device */
+int ecfft_comm_stats_enable(ecfft_comm* comm, int on);
+int ecfft_comm_stats_read(ecfft_comm* comm, double* comm_ms, double* exchanges, double* bytes_sent);
+int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, void* stream);
+int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
+int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 
 /* Pointwise building block of the multi-GPU ENTER / EXIT (no reference counterpart): with T = table `which` (one of
  * ECFFT_TBL_XNN_S .. ECFFT_TBL_Z1Z1_REM_XNN_S) of the subtree with m leaves,
@@ -156,6 +185,10 @@ int ecfft_selftest_field(int field, int op, const void* a, const void* b, const 
  * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot
  * path against beside the HBM roofline. */
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s);
+
+/* synchronous copy on the CURRENT device: kind 0 device -> host, 1 host -> device, 2 device -> device.  Lets a host language
+ * without HIP bindings implement the exchange callback above — ecfft_amd/distributed.py does, over gloo. */
+int ecfft_device_copy(void* dst, const void* src, size_t bytes, int kind);
 
 /* library / device identification for logs: writes a NUL-terminated string */
 int ecfft_device_info(int device, char* buf, size_t cap);

@@ -1,6 +1,9 @@
 """Worker for the GPU leg of tests/test_distributed.py: torch.distributed.run, gloo backend, every rank on cuda:0.
-Runs the multi-GPU code path with the REAL local ops (HIP kernels through the C-ABI on device tensors) and compares with
-the single-GPU transforms of the same context: split EXTEND, sharded ENTER, sharded EXIT."""
+Runs the C++ multi-GPU path of the C ABI (ecfft_extend_sharded / ecfft_enter_sharded / ecfft_exit_sharded: index maps,
+pack / unpack operators, cyclic-shard stage kernels, block-local fused passes) with a CALLBACK transport — the exchanges are
+torch.distributed point-to-point calls staged through host memory, because RCCL refuses several ranks on one device — and
+compares every rank's shard with the single-GPU transforms of the same context, bit for bit.  The Python model of the same
+algorithm (ecfft_amd.distributed.extend_sharded with HipOps) is run next to it for the split EXTEND."""
 import os
 import sys
 
@@ -29,29 +32,38 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     ok = True
-    groups = D.make_groups()
+    comm = D.Comm.callback()
+    assert comm.rank == rank and comm.world == world
     for field, n in (("secp256k1", 1 << 13), ("m31", 1 << 16)):
         F = ecfft_amd.FIELDS[field]
         tree = F.build_fftree(2 * n)
-        ops = D.HipOps(tree)
         x = synth(field, n, 11)                                            # same on every rank
         view = np.int64 if field == "secp256k1" else np.int32
         c = n // world
         mine = torch.from_numpy(x[rank * c:(rank + 1) * c].view(view).reshape(c, -1).copy()).cuda()
         full = torch.from_numpy(x.view(view).reshape(n, -1).copy()).cuda()
-        # split EXTEND == single-GPU EXTEND
+
+        def check(what, got, want):
+            good = torch.equal(got, want[rank * c:(rank + 1) * c])
+            if not good:
+                print(f"rank {rank}: {field} {what} MISMATCH", flush=True)
+            return good
+        # split EXTEND == single-GPU EXTEND (C++ path and the Python model)
         for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
             want = tree.extend(full, moiety)
-            got = D.extend_sharded(ops, mine.clone(), n, moiety)
-            ok = ok and torch.equal(got, want[rank * c:(rank + 1) * c])
-        # sharded ENTER / EXIT == single-GPU ENTER / EXIT
-        want = tree.enter(full)
-        got = D.enter_sharded(ops, mine.clone(), n, groups)
-        ok = ok and torch.equal(got, want[rank * c:(rank + 1) * c])
-        want = tree.exit(full)
-        got = D.exit_sharded(ops, mine.clone(), n, groups)
-        ok = ok and torch.equal(got, want[rank * c:(rank + 1) * c])
+            ok = check(f"extend_sharded {moiety}", tree.extend_sharded(comm, mine.clone(), n, moiety), want) and ok
+            ok = check(f"model extend {moiety}", D.extend_sharded(D.HipOps(tree), mine.clone(), n, moiety), want) and ok
+        # in place (in == out is allowed by the ABI): run through the raw call
+        buf = mine.clone()
+        ecfft_amd.fftree._check(ecfft_amd.lib().ecfft_extend_sharded(tree._h, comm._h, buf.data_ptr(), buf.data_ptr(), n, 1,
+                                                                      torch.cuda.current_stream().cuda_stream))
+        ok = check("extend_sharded in place", buf, tree.extend(full, ecfft_amd.Moiety.S1)) and ok
+        # sharded ENTER / EXIT == single-GPU ENTER / EXIT (EXIT of arbitrary evaluations, not only of ENTER outputs)
+        ok = check("enter_sharded", tree.enter_sharded(comm, mine.clone(), n), tree.enter(full)) and ok
+        ok = check("exit_sharded", tree.exit_sharded(comm, mine.clone(), n), tree.exit(full)) and ok
         torch.cuda.synchronize()
+    st = comm.stats()
+    ok = ok and st["exchanges"] > 0
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

@@ -39,6 +39,34 @@ def test_sharded_transforms_with_hip_ops(world):
 
 
 @pytest.mark.gpu
+def test_sharded_transforms_over_rccl_single_rank():
+    """the C++ sharded path over the REAL RCCL transport (librccl loaded at run time, ncclGetUniqueId / ncclCommInitRank,
+    grouped ncclSend / ncclRecv on the HIP stream).  The GPU box has one GPU, so world = 1: every exchange is a self
+    send / receive and log P = 0, but communicator creation, the pack / unpack operators and all four exchange calls of a
+    split EXTEND really run on RCCL.  Results must equal the single-GPU transforms."""
+    import torch
+    import ecfft_amd
+    from ecfft_amd import distributed as D
+    comm = D.Comm.rccl(device=0, world=1, rank=0)
+    assert comm.world == 1 and comm.rank == 0
+    comm.stats(True)
+    for field, n in (("secp256k1", 1 << 12), ("m31", 1 << 15)):
+        tree = ecfft_amd.FIELDS[field].build_fftree(2 * n)
+        rng = np.random.default_rng(3)
+        if field == "m31":
+            x = torch.from_numpy(rng.integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+        else:
+            a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+            x = torch.from_numpy(a.view(np.int64)).cuda()
+        for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+            assert torch.equal(tree.extend_sharded(comm, x, n, moiety), tree.extend(x, moiety))
+        assert torch.equal(tree.enter_sharded(comm, x, n), tree.enter(x))
+        assert torch.equal(tree.exit_sharded(comm, x, n), tree.exit(x))
+    st = comm.stats()
+    assert st["exchanges"] >= 16 and st["bytes_sent"] > 0 and st["comm_ms"] > 0      # 4 per EXTEND x 2 moieties x 2 fields
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("secp256k1", 1 << 8, 2),
                                            ("secp256k1", 1 << 22, 3)])   # last: BASELINE configs[3] size, P = 8
 def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
