@@ -71,7 +71,8 @@ def cpu_baseline(field, log_n):
     assert np.array_equal(back, c)
     we, wx = w_mul(n)
     return {"value": (we + wx) / (t2 - t0), "unit": "field-mul/s", "cores": 1, "kind": "port",
-            "sample": f"{field} n=2^{log_n} one ENTER ({t1 - t0:.3f}s) + one EXIT ({t2 - t1:.3f}s), oracle/ C restatement, 1 thread",
+            "sample": f"{field} n=2^{log_n} one ENTER ({t1 - t0:.3f}s) + one EXIT ({t2 - t1:.3f}s), oracle/ C restatement of the reference's "
+                      f"recursive algorithm (per-call vectors from a per-thread size-class cache), 1 thread",
             "host_cpu": _cpu_name()}
 
 
@@ -106,7 +107,8 @@ def cpu_baseline_socket(field, log_n):
     assert all(ok)
     we, wx = w_mul(n)
     return {"value": cores * (we + wx) / dt, "unit": "field-mul/s", "cores": cores, "kind": "port",
-            "sample": f"{field} n=2^{log_n}: {cores} independent ENTER+EXIT round trips, one per thread, {dt:.3f}s wall", "host_cpu": _cpu_name()}
+            "sample": f"{field} n=2^{log_n}: {cores} independent ENTER+EXIT round trips, one per thread on the physical cores of one socket, "
+                      f"{dt:.3f}s wall (allocations served by per-thread caches: compute-bound, no mmap / page-fault contention)", "host_cpu": _cpu_name()}
 
 
 def _cpu_name():
@@ -222,33 +224,7 @@ def main():
         tree.profile(False)
         split = {"enter_ms": (te1 - te0) * 1e3 / args.steps, "exit_ms": (te2 - te1) * 1e3 / args.steps,
                  "instrumented_ms_per_step": (te2 - te0) * 1e3 / args.steps}
-        tot_alg = sum(c["alg_bytes"] for c in classes)
-        dom = max(classes, key=lambda c: c["ms"])
-        if dom["launches"]:
-            ach = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "note": "achieved = ALGORITHMIC bytes (stage-streaming model, SURVEY 8(d)) / measured launch time: an effective "
-                                "bandwidth; the fused kernel really moves `traffic` bytes per launch and is integer-VALU bound (DESIGN.md 4)",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": _traffic(dom["name"]),
-                        "launches_per_step": dom["launches"] / args.steps,
-                        "avg_launch_us": dom["ms"] * 1e3 / dom["launches"],
-                        "alg_bytes_per_launch": dom["alg_bytes"] / dom["launches"],
-                        "share_of_event_time": dom["ms"] / max(sum(c["ms"] for c in classes), 1e-12),
-                        "whole_job_alg_GBs": sum(b_alg(n, F.elem_bytes)) / (elapsed / args.steps) / 1e9,
-                        "kernels": [{k: c[k] for k in ("name", "launches", "ms", "alg_bytes")} for c in classes if c["launches"]]}
-            be, bx = b_alg(n, F.elem_bytes)
-            roofline["alg_bytes_check"] = {"profiler_sum_per_step": tot_alg / args.steps, "closed_form": be + bx}
-            # the binding resource is the integer VALU: price the executed multiplies against the bare multiply chain
-            # measured now on this chip at the kernels' occupancy (4 waves/SIMD)
-            try:
-                ceil4 = F.mul_ceiling(4, local_rank)
-                xe_, xx_ = executed_mul(n)
-                roofline["valu"] = {"bound": "integer VALU (modular multiply)", "executed_mul_per_step": xe_ + xx_,
-                                    "achieved": (xe_ + xx_) / (elapsed / args.steps), "peak": ceil4, "unit": "mul/s",
-                                    "frac": (xe_ + xx_) / (elapsed / args.steps) / ceil4,
-                                    "note": "peak = ecfft_mul_ceiling: the kernels' table multiply as a bare dependent chain, 4 waves/SIMD, whole chip"}
-            except Exception as ex:  # pragma: no cover
-                roofline["valu"] = {"error": str(ex)}
+        roofline = build_roofline(args, F, n, classes, elapsed / args.steps, local_rank)
 
     # ---- extra: batched throughput (B independent polynomials share every launch; not the headline value) -----
     batched = None
@@ -276,6 +252,9 @@ def main():
             "value": value, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+            "value_note": "reference-equivalent throughput: the ALGORITHMIC multiply count of the reference's recursion (SURVEY 8(d)) per second; "
+                          "the kernels execute about half as many multiplies (normalised butterflies) — see executed_field_mul_per_s",
+            "executed_field_mul_per_s": sum(executed_mul(n)) * args.steps * world / elapsed,
             "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT (BASELINE.json configs[2])" if args.log_n == 20 and args.field == "secp256k1"
                        else f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT",
                        "n": n, "field": args.field, "parallelism": f"{world} independent polynomial(s), one per GPU, no collective",
@@ -424,14 +403,107 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
         dist.barrier(); dist.destroy_process_group()
 
 
-def _traffic(kernel):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/traffic.json), else None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+INSTR_PER_MUL = {"secp256k1": 169, "m31": 6}     # VALU instructions of the kernels' table multiply-add (tools/gen_mulmod_asm.py; field_m31.h)
+N_SIMD = 256 * 4
+
+
+def _counters(field, log_n):
+    """per-class rocprofv3 counters of this workload from the newest committed PMC pass (profiles/r*/counters_<field>_<log n>.json,
+    produced by tools/prof_counters.sh), else None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"counters_{field}_{log_n}.json")))
+    if not files:
+        return None, None
     try:
-        with open(path) as f:
-            return json.load(f).get(kernel)
+        with open(files[-1]) as f:
+            return json.load(f), os.path.relpath(files[-1], ROOT)
     except (OSError, ValueError):
+        return None, None
+
+
+def build_roofline(args, F, n, classes, step_s, device):
+    """`roofline` object of the bench line.  What binds this path is decided from evidence, not assumed:
+      * HBM: REAL bytes per launch from rocprofv3 PMC counters (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) over the
+        launch time measured NOW with HIP events -> `achieved` / `frac` against the 8 TB/s line (top level = dominant kernel);
+      * VALU: wave-instructions per launch from SQ_INSTS_VALU over the same time and the shader clock measured NOW under
+        the multiply load -> issue cycles per instruction per SIMD, against the cycles the bare multiply chain needs at full
+        occupancy on this chip (`valu_issue`), and executed field multiplies per second against that chain (`valu`);
+      * the stage-streaming figure of SURVEY 8(d) (algorithmic bytes / time) is kept as `effective`: the fused kernels run
+        >= 10 stages per HBM round trip, so it can exceed the HBM line — it is a figure of merit, never a fraction."""
+    live = [c for c in classes if c["launches"]]
+    if not live:
         return None
+    dom = max(live, key=lambda c: c["ms"])
+    ctr, src = _counters(args.field, args.log_n)
+    cls_ctr = (ctr or {}).get("classes", {})
+    per_class = []
+    tot_bytes = tot_insts = 0.0
+    complete = bool(cls_ctr)
+    for c in live:
+        lps = c["launches"] / args.steps
+        us = c["ms"] * 1e3 / c["launches"]
+        row = {"name": c["name"], "launches_per_step": lps, "avg_launch_us": us, "event_ms_per_step": c["ms"] / args.steps,
+               "effective_GBs": c["alg_bytes"] / (c["ms"] * 1e-3) / 1e9, "alg_bytes_per_launch": c["alg_bytes"] / c["launches"]}
+        k = cls_ctr.get(c["name"])
+        if k and "hbm_bytes_per_launch" in k:
+            row["hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+            row["hbm_counter_GBs"] = k["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
+            row["hbm_frac"] = row["hbm_counter_GBs"] / HBM_PEAK_GBS
+            row["hbm_counter_GBs_solo"] = k["hbm_bytes_per_launch"] / (k.get("pmc_avg_us", us) * 1e-6) / 1e9
+            tot_bytes += k["hbm_bytes_per_launch"] * lps
+        else:
+            complete = False
+        if k and "SQ_INSTS_VALU" in k:
+            row["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
+            tot_insts += k["SQ_INSTS_VALU"] * lps
+            if k.get("SQ_WAVE_CYCLES"):
+                row["wave_cycles_waiting_frac"] = k.get("SQ_WAIT_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+                row["wave_cycles_issue_stalled_frac"] = k.get("SQ_WAIT_INST_ANY", 0.0) / k["SQ_WAVE_CYCLES"]
+        else:
+            complete = False
+        per_class.append(row)
+    drow = next(r for r in per_class if r["name"] == dom["name"])
+    be, bx = b_alg(n, F.elem_bytes)
+    out = {"kernel": dom["name"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "achieved": drow.get("hbm_counter_GBs"), "frac": drow.get("hbm_frac"), "traffic": drow.get("hbm_bytes_per_launch"),
+           "launches_per_step": drow["launches_per_step"], "avg_launch_us": drow["avg_launch_us"],
+           "share_of_event_time": dom["ms"] / max(sum(c["ms"] for c in live), 1e-12),
+           "effective": {"GBs": drow["effective_GBs"], "alg_bytes_per_launch": drow["alg_bytes_per_launch"],
+                         "whole_job_GBs": (be + bx) / step_s / 1e9,
+                         "alg_bytes_check": {"profiler_sum_per_step": sum(c["alg_bytes"] for c in live) / args.steps, "closed_form": be + bx},
+                         "note": "ALGORITHMIC bytes of the stage-streaming model (SURVEY 8(d)) / measured time; >= 10 stages share one HBM "
+                                 "round trip in the fused kernels, so this can exceed the HBM line and is not a fraction of it"},
+           "per_class": per_class, "counters_source": src,
+           "note": "achieved / frac / traffic: HBM bytes really moved per launch of the dominant kernel (rocprofv3 PMC, committed under "
+                   "profiles/) over its launch time measured in this run with HIP events"}
+    try:
+        clock_mhz = F.shader_clock_mhz(device)
+        ceil4, ceil8 = F.mul_ceiling(4, device), F.mul_ceiling(8, device)
+        xe_, xx_ = executed_mul(n)
+        out["clock_mhz_under_multiply_load"] = clock_mhz
+        out["valu"] = {"executed_mul_per_step": xe_ + xx_, "achieved": (xe_ + xx_) / step_s, "peak": max(ceil4, ceil8), "unit": "mul/s",
+                       "frac": (xe_ + xx_) / step_s / max(ceil4, ceil8), "peak_at_4_waves_per_simd": ceil4, "peak_at_8_waves_per_simd": ceil8,
+                       "note": "peak = ecfft_mul_ceiling: the kernels' table multiply as a bare dependent chain on the whole chip"}
+        if tot_insts:
+            ipm = INSTR_PER_MUL[args.field]
+            floor = clock_mhz * 1e6 * N_SIMD * 64 / (max(ceil4, ceil8) * ipm)     # cycles per wave-instruction per SIMD of the bare chain
+            measured = step_s * clock_mhz * 1e6 * N_SIMD / tot_insts
+            out["valu_issue"] = {"valu_wave_insts_per_step": tot_insts, "cycles_per_inst_per_simd": measured,
+                                 "floor_cycles_per_inst_per_simd": floor, "frac": floor / measured,
+                                 "note": "SQ_INSTS_VALU summed over every launch of a step (PMC pass) against step time x measured clock x 1024 SIMDs; "
+                                         "floor = the same quantity for the bare multiply chain (integer mad / carry instructions issue at ~4 cycles, "
+                                         "tools/ubench/clock.hip)"}
+    except Exception as ex:  # pragma: no cover
+        out["valu"] = {"error": str(ex)}
+    if tot_bytes and complete:
+        out["whole_job"] = {"hbm_counter_GBs": tot_bytes / step_s / 1e9, "hbm_frac": tot_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                            "hbm_bytes_per_step": tot_bytes}
+    # what binds: the larger of the two measured fractions
+    hb = (out.get("whole_job") or {}).get("hbm_frac") or out.get("frac") or 0.0
+    vb = max((out.get("valu_issue") or {}).get("frac", 0.0), (out.get("valu") or {}).get("frac", 0.0))
+    out["bound"] = "valu" if vb >= hb else "hbm"
+    out["bound_evidence"] = {"hbm_frac_of_8TBs": hb, "valu_frac_of_multiply_chain": vb}
+    return out
 
 
 if __name__ == "__main__":

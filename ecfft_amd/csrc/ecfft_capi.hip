@@ -348,6 +348,50 @@ __global__ __launch_bounds__(256) void k_mul_chain(const typename F::elem* t, ty
     x[g] = F::canon(xv);
 }
 
+// the same chain with shader-clock (s_memtime) and constant 100 MHz (wall_clock64) stamps around it: effective shader clock
+// of the chip while every SIMD runs the kernels' multiply — what DVFS really grants under this instruction mix
+struct ClockStamp { unsigned long long cyc, wall; };
+template <class F>
+__global__ __launch_bounds__(256) void k_clock_probe(const typename F::elem* t, typename F::elem* x, ClockStamp* st, int iters) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    typename F::telem tv = F::to_table(t[g]);
+    typename F::elem xv = x[g], cv = t[g];
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) xv = F::tmul_add(tv, xv, cv);
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+    x[g] = F::canon(xv);
+    if (threadIdx.x == 0) { st[blockIdx.x].cyc = c1 - c0; st[blockIdx.x].wall = w1 - w0; }
+}
+template <class F>
+int run_shader_clock(int device, double* mhz) {
+    using E = typename F::elem;
+    if (!mhz) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    hipDeviceProp_t p;
+    if (!dev.ok || hipGetDeviceProperties(&p, device) != hipSuccess) return ECFFT_ERR_HIP;
+    const int blocks = p.multiProcessorCount * 4, iters = sizeof(E) == 32 ? 2048 : 65536;    // a few ms at 4 waves per SIMD
+    const size_t n = (size_t)blocks * 256;
+    std::vector<E> h(n);
+    memset(h.data(), 0x35, n * sizeof(E));
+    E *dt = nullptr, *dx = nullptr; ClockStamp* ds = nullptr;
+    std::vector<ClockStamp> hs(blocks);
+    bool ok = hipMalloc(&dt, n * sizeof(E)) == hipSuccess && hipMalloc(&dx, n * sizeof(E)) == hipSuccess && hipMalloc(&ds, blocks * sizeof(ClockStamp)) == hipSuccess &&
+              hipMemcpy(dt, h.data(), n * sizeof(E), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, h.data(), n * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
+    for (int r = 0; ok && r < 2; ++r) {
+        hipLaunchKernelGGL(k_clock_probe<F>, dim3(blocks), dim3(256), 0, nullptr, (const E*)dt, dx, ds, iters);
+        ok = hipDeviceSynchronize() == hipSuccess;
+    }
+    ok = ok && hipMemcpy(hs.data(), ds, blocks * sizeof(ClockStamp), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(dt); (void)hipFree(dx); (void)hipFree(ds);
+    if (!ok) return ECFFT_ERR_HIP;
+    double cyc = 0, wall = 0;
+    for (const ClockStamp& c : hs) { cyc += (double)c.cyc; wall += (double)c.wall; }
+    *mhz = wall > 0 ? cyc / wall * 100.0 : 0.0;
+    return ECFFT_OK;
+}
+
 template <class F>
 int run_mul_ceiling(int device, int waves_per_simd, double* mul_per_s) {
     using E = typename F::elem;
@@ -733,6 +777,12 @@ int ecfft_selftest_field(int field, int op, const void* a, const void* b, const 
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);
+    return ECFFT_ERR_BAD_ARG;
+}
+
+int ecfft_shader_clock(int field, int device, double* mhz) {
+    if (field == ECFFT_FIELD_SECP256K1) return run_shader_clock<Secp256k1>(device, mhz);
+    if (field == ECFFT_FIELD_M31) return run_shader_clock<M31>(device, mhz);
     return ECFFT_ERR_BAD_ARG;
 }
 

@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -103,6 +103,7 @@ def lib():
         L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
         L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
+        L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
         L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
         L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
@@ -157,6 +158,12 @@ class Field:
         """field multiplies per second of the kernels' table multiply as a bare dependent chain on the whole chip"""
         r = ctypes.c_double()
         _check(lib().ecfft_mul_ceiling(self.id, device, waves_per_simd, ctypes.byref(r)))
+        return r.value
+
+    def shader_clock_mhz(self, device=0):
+        """effective shader clock while the whole chip runs this field's table multiply"""
+        r = ctypes.c_double()
+        _check(lib().ecfft_shader_clock(self.id, device, ctypes.byref(r)))
         return r.value
 
     def to_standard(self, a):

@@ -186,6 +186,11 @@ int ecfft_selftest_field(int field, int op, const void* a, const void* b, const 
  * path against beside the HBM roofline. */
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s);
 
+/* Measurement hook: effective shader clock in MHz while every SIMD of the chip runs the kernels' table multiply (ratio of
+ * s_memtime ticks to the constant 100 MHz wall clock inside that kernel) — the clock DVFS grants this instruction mix, needed
+ * to turn rocprofv3 instruction counts into issue-cycle fractions. */
+int ecfft_shader_clock(int field, int device, double* mhz);
+
 /* synchronous copy on the CURRENT device: kind 0 device -> host, 1 host -> device, 2 device -> device.  Lets a host language
  * without HIP bindings implement the exchange callback above — ecfft_amd/distributed.py does, over gloo. */
 int ecfft_device_copy(void* dst, const void* src, size_t bytes, int kind);

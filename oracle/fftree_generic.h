@@ -48,7 +48,36 @@ typedef struct fftree {
 
 enum { MOIETY_S0 = 0, MOIETY_S1 = 1 }; /* src/fftree.rs:17-21 */
 
-static fe* fe_alloc(size_t n) { fe* p = (fe*)calloc(n ? n : 1, sizeof(fe)); if (!p) abort(); return p; }
+/* Every vector of the recursion is a fresh zero-initialised allocation that is released when its function returns, like
+ * the reference's Vec<F>s.  With glibc that is an mmap / page-fault / munmap cycle per large vector, which serialises on the
+ * kernel's address-space lock when many threads run transforms at once (the 64-thread socket baseline of bench.py scaled
+ * 13x).  A per-thread size-class cache keeps the allocation PATTERN (same calls, same zeroing) but takes the system calls
+ * out of the timed path, so the socket figure is bound by the field arithmetic.  ECFFT_ORACLE_POOL=0 restores plain
+ * calloc / free. */
+typedef struct ora_blk { struct ora_blk* next; size_t bin; } ora_blk;          /* 16-byte header in front of the payload */
+#define ORA_NBINS 48
+static __thread ora_blk* ora_bins[ORA_NBINS];
+static int ora_pool_enabled(void) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ECFFT_ORACLE_POOL"); on = !(e && e[0] == '0'); }
+    return on;
+}
+static fe* fe_alloc(size_t n) {
+    size_t bytes = (n ? n : 1) * sizeof(fe);
+    unsigned bin = 0; while (((size_t)1 << bin) < bytes) ++bin;
+    ora_blk* b = NULL;
+    if (ora_pool_enabled() && bin < ORA_NBINS && ora_bins[bin]) { b = ora_bins[bin]; ora_bins[bin] = b->next; }
+    else { b = (ora_blk*)malloc(sizeof(ora_blk) + ((size_t)1 << bin)); if (!b) abort(); }
+    b->bin = bin; b->next = NULL;
+    memset(b + 1, 0, bytes);
+    return (fe*)(b + 1);
+}
+static void fe_free(fe* p) {
+    if (!p) return;
+    ora_blk* b = (ora_blk*)p - 1;
+    if (ora_pool_enabled() && b->bin < ORA_NBINS) { b->next = ora_bins[b->bin]; ora_bins[b->bin] = b; }
+    else free(b);
+}
 
 static unsigned ilog2_sz(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
 
@@ -90,7 +119,7 @@ static void batch_inversion(fe* v, size_t n) {
     size_t np = 0;
     fe acc = fe_one();
     for (size_t i = 0; i < n; ++i) { if (fe_is_zero(v[i])) continue; acc = fe_mul(acc, v[i]); prod[np++] = acc; }
-    if (np == 0) { free(prod); return; }
+    if (np == 0) { fe_free(prod); return; }
     acc = fe_inv(acc);
     for (size_t i = n; i-- > 0;) {
         if (fe_is_zero(v[i])) continue;
@@ -100,7 +129,7 @@ static void batch_inversion(fe* v, size_t n) {
         v[i] = fe_mul(acc, below);
         acc = newacc;
     }
-    free(prod);
+    fe_free(prod);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -132,7 +161,7 @@ static fe* extend_impl(const fftree* t, const fe* evals, size_t n, int moiety) {
     skip = (moiety == MOIETY_S0) ? 0 : 1;                      /* :108-111 */
     for (size_t i = 0; i < h; ++i)                             /* :104-118 */
         mat2_apply(&R[2 * i + skip], e0p[i], e1p[i], &res[i], &res[i + h]);
-    free(e0); free(e1); free(e0p); free(e1p);
+    fe_free(e0); fe_free(e1); fe_free(e0p); fe_free(e1p);
     return res;
 }
 static fe* tree_extend(const fftree* t, const fe* evals, size_t n, int moiety) { /* :123-126 */
@@ -168,7 +197,7 @@ static fe* enter_impl(const fftree* t, const fe* coeffs, size_t n) {
         res[2 * i] = fe_add(u0[i], fe_mul(v0[i], t->xnn_s[2 * i]));
         res[2 * i + 1] = fe_add(u1[i], fe_mul(v1[i], t->xnn_s[2 * i + 1]));
     }
-    free(u0); free(v0); free(u1); free(v1);
+    fe_free(u0); fe_free(v0); fe_free(u1); fe_free(v1);
     return res;
 }
 static fe* tree_enter(const fftree* t, const fe* coeffs, size_t n) { /* :164-167 */
@@ -197,14 +226,14 @@ static fe* redc_impl(const fftree* t, const fe* evals, const fe* a, size_t n, in
     fe* h0 = extend_impl(t, h1, h, moiety);                    /* :256 */
     fe* res = fe_alloc(n);
     for (size_t i = 0; i < h; ++i) { res[2 * i] = h0[i]; res[2 * i + 1] = h1[i]; } /* :258 */
-    free(e0); free(e1); free(a0_inv); free(a1); free(t0); free(g1); free(h1); free(h0);
+    fe_free(e0); fe_free(e1); fe_free(a0_inv); fe_free(a1); fe_free(t0); fe_free(g1); fe_free(h1); fe_free(h0);
     return res;
 }
 static fe* modular_reduce_impl(const fftree* t, const fe* evals, const fe* a, const fe* c, size_t n) {
     fe* h = redc_impl(t, evals, a, n, MOIETY_S0);              /* :278 */
     for (size_t i = 0; i < n; ++i) h[i] = fe_mul(h[i], c[i]);  /* :279 */
     fe* r = redc_impl(t, h, a, n, MOIETY_S0);                  /* :280 */
-    free(h);
+    fe_free(h);
     return r;
 }
 static fe* tree_modular_reduce(const fftree* t, const fe* evals, const fe* a, const fe* c, size_t n) {
@@ -222,7 +251,7 @@ static fe* exit_impl(const fftree* t, const fe* evals, size_t n) {
     fe* mr = modular_reduce_impl(t, evals, t->xnn_s, t->z0z0_rem_xnn_s, n); /* :206-207 */
     fe* u0 = fe_alloc(h);
     for (size_t i = 0; i < h; ++i) u0[i] = mr[2 * i];          /* :208-210 */
-    free(mr);
+    fe_free(mr);
     const fftree* st = t->subtree;
     fe* a = exit_impl(st, u0, h);                              /* :213 */
     fe* v0 = fe_alloc(h);
@@ -230,7 +259,7 @@ static fe* exit_impl(const fftree* t, const fe* evals, size_t n) {
         v0[i] = fe_mul(fe_sub(evals[2 * i], u0[i]), t->xnn_s_inv[2 * i]);
     fe* b = exit_impl(st, v0, h);                              /* :220 */
     memcpy(res, a, h * sizeof(fe)); memcpy(res + h, b, h * sizeof(fe)); /* :222 */
-    free(u0); free(a); free(v0); free(b);
+    fe_free(u0); fe_free(a); fe_free(v0); fe_free(b);
     return res;
 }
 static fe* tree_exit(const fftree* t, const fe* evals, size_t n) { /* :227-230 */
@@ -255,9 +284,9 @@ static size_t degree_impl(const fftree* t, const fe* evals, size_t n) {
         for (size_t i = 0; i < h; ++i) t1[i] = fe_mul(fe_sub(e1[i], g1[i]), t->z0_inv_s1[i]);
         fe* t0 = extend_impl(t, t1, h, MOIETY_S0);
         r = h + degree_impl(t->subtree, t0, h);
-        free(t1); free(t0);
+        fe_free(t1); fe_free(t0);
     }
-    free(e0); free(e1); free(g1);
+    fe_free(e0); fe_free(e1); fe_free(g1);
     return r;
 }
 
@@ -279,7 +308,7 @@ static fe* vanish_impl(const fftree* t, const fe* dom, size_t n) {
     for (size_t i = 0; i < n; ++i) q_s0[i] = fe_mul(qp[i], qpp[i]); /* :303 */
     fe* q_s1 = tree_mextend(t, q_s0, n, MOIETY_S1);            /* :304 */
     for (size_t i = 0; i < n; ++i) { res[2 * i] = q_s0[i]; res[2 * i + 1] = q_s1[i]; } /* :305-307 */
-    free(qp); free(qpp); free(q_s0); free(q_s1);
+    fe_free(qp); fe_free(qpp); fe_free(q_s0); fe_free(q_s1);
     return res;
 }
 static fe* tree_vanish(const fftree* t, const fe* dom, size_t n) { /* :313-316 */
@@ -293,9 +322,9 @@ static fe* tree_vanish(const fftree* t, const fe* dom, size_t n) { /* :313-316 *
 static void tree_free(fftree* t) {
     if (!t) return;
     tree_free(t->subtree);
-    free(t->f); free(t->recombine); free(t->decompose); free(t->maps);
-    free(t->xnn_s); free(t->xnn_s_inv); free(t->z0_s1); free(t->z1_s0);
-    free(t->z0_inv_s1); free(t->z1_inv_s0); free(t->z0z0_rem_xnn_s); free(t->z1z1_rem_xnn_s);
+    fe_free(t->f); free(t->recombine); free(t->decompose); free(t->maps);
+    fe_free(t->xnn_s); fe_free(t->xnn_s_inv); fe_free(t->z0_s1); fe_free(t->z1_s0);
+    fe_free(t->z0_inv_s1); fe_free(t->z1_inv_s0); fe_free(t->z0z0_rem_xnn_s); fe_free(t->z1z1_rem_xnn_s);
     free(t);
 }
 
@@ -379,10 +408,10 @@ static fftree* from_tree(fe* f, size_t n, const ratmap* maps, int nmaps) {
         fe* st_z0_s1 = tree_extend(t, st_z0_s0, hn, MOIETY_S1); /* :391 */
         fe* st_z1_s1 = tree_extend(t, st_z1_s0, hn, MOIETY_S1); /* :392 */
         for (size_t i = 0; i < hn; ++i) t->z0_s1[i] = fe_mul(st_z0_s1[i], st_z1_s1[i]); /* :393 */
-        free(st_z0_s0); free(st_z1_s0); free(st_z0_s1); free(st_z1_s1);
+        fe_free(st_z0_s0); fe_free(st_z1_s0); fe_free(st_z0_s1); fe_free(st_z1_s1);
         fe* z1_s = tree_vanish(t, s1, hn);                     /* :396 */
         for (size_t i = 0; i < hn; ++i) t->z1_s0[i] = z1_s[2 * i]; /* :397 */
-        free(z1_s);
+        fe_free(z1_s);
     } else if (n == 2) {
         t->z0_s1[0] = fe_sub(s1[0], s0[0]);                    /* :401 */
         t->z1_s0[0] = fe_sub(s0[0], s1[0]);                    /* :402 */
@@ -418,13 +447,13 @@ static fftree* from_tree(fe* f, size_t n, const ratmap* maps, int nmaps) {
         }
         fe* r = tree_modular_reduce(t, z1z1, t->xnn_s, t->z0z0_rem_xnn_s, n); /* :452 */
         memcpy(t->z1z1_rem_xnn_s, r, n * sizeof(fe));
-        free(sq_s0); free(zz_nnnn_s0); free(zz_nnnn_s1); free(zz_nnnn_s); free(tmp); free(div_rem);
-        free(z1z1); free(r);
+        fe_free(sq_s0); fe_free(zz_nnnn_s0); fe_free(zz_nnnn_s1); fe_free(zz_nnnn_s); fe_free(tmp); fe_free(div_rem);
+        fe_free(z1z1); fe_free(r);
     } else if (n == 2) {
         t->z0z0_rem_xnn_s[0] = t->z0z0_rem_xnn_s[1] = fe_sqr(s0[0]); /* :456 */
         t->z1z1_rem_xnn_s[0] = t->z1z1_rem_xnn_s[1] = fe_sqr(s1[0]); /* :457 */
     }
-    free(xnnnn_s); free(xnnnn_s_inv); free(s0); free(s1);
+    fe_free(xnnnn_s); fe_free(xnnnn_s_inv); fe_free(s0); fe_free(s1);
     return t;
 }
 
@@ -552,7 +581,7 @@ void* ORA(tree_new)(const void* leaves, size_t n, const void* nums3, const void*
 }
 #define ORA_WRAP_OUT(expr, count)                                         \
     do { fe* r_ = (expr); if (!r_) return -1;                             \
-         memcpy(out, r_, (count) * sizeof(fe)); free(r_); return 0; } while (0)
+         memcpy(out, r_, (count) * sizeof(fe)); fe_free(r_); return 0; } while (0)
 
 int ORA(extend)(const void* t, const void* in, void* out, size_t e, int moiety) {
     if (!e || (e & (e - 1))) return -2;

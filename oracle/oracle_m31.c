@@ -145,7 +145,7 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
     fe* leaves = fe_alloc(n);
     ec_leaves(&w, offset, gen, leaves, n);                     /* :546-551 */
     fftree* t = tree_new(leaves, n, maps, (int)log_n);
-    free(maps); free(leaves);
+    free(maps); fe_free(leaves);
     return t;
 }
 void ORA(from_std)(const void* in, void* out, size_t n) { memcpy(out, in, n * sizeof(fe)); }

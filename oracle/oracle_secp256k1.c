@@ -76,7 +76,7 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
     goodcurve cur = curve; ecpoint g = gen;
     for (unsigned k = 0; k < log_n; ++k) {
         goodcurve next;
-        if (!good_isogeny(&cur, &next, &maps[k])) { free(maps); free(leaves); return NULL; }
+        if (!good_isogeny(&cur, &next, &maps[k])) { free(maps); fe_free(leaves); return NULL; }
         if (check_chain) {
             wcurve wc = goodcurve_w(&cur), wn = goodcurve_w(&next);
             ecpoint gp = good_isogeny_map(&cur, &maps[k], g);
@@ -87,7 +87,7 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
         cur = next;
     }
     fftree* t = tree_new(leaves, n, maps, (int)log_n);
-    free(maps); free(leaves);
+    free(maps); fe_free(leaves);
     return t;
 }
 /* Montgomery <-> standard form (little-endian 32 bytes per element) */

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One hot-path case, nothing else, for rocprofv3: builds the tree, then runs `reps` calls of one operation on
 device-resident data.  tools/prof_case.sh wraps it with kernel-trace and PMC passes.
-usage: prof_case.py FIELD LOG_N OP [REPS]     OP = enter | exit | extend | both"""
+usage: prof_case.py FIELD LOG_N OP [REPS] [--count FILE]     OP = enter | exit | extend | both
+--count FILE: instead of the plain reps, run ONE rep with the library's per-launch profiler on and write the number of
+launches per kernel class of that rep to FILE (tools/counters_json.py uses it to cut the timed launches out of a trace)."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,13 +13,37 @@ import ecfft_amd
 from bench import synth
 
 field, log_n, op = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+reps = int(sys.argv[4]) if len(sys.argv) > 4 and not sys.argv[4].startswith("--") else 3
+count_file = sys.argv[sys.argv.index("--count") + 1] if "--count" in sys.argv else None
 n = 1 << log_n
 F = ecfft_amd.FIELDS[field]
 tree = F.build_fftree(2 * n if op == "extend" else n)
 h = synth(field, n, 7)
 x = torch.from_numpy(h.view(np.int64) if field == "secp256k1" else h.view(np.int32)).cuda()
 torch.cuda.synchronize()
+
+
+def one():
+    if op == "enter":
+        return tree.enter(x)
+    if op == "exit":
+        return tree.exit(x)
+    if op == "extend":
+        return tree.extend(x, ecfft_amd.Moiety.S1)
+    return tree.exit(tree.enter(x))
+
+
+if count_file:
+    import json
+    one(); torch.cuda.synchronize()
+    tree.profile(True)
+    one(); torch.cuda.synchronize()
+    classes = tree.profile_read()
+    tree.profile(False)
+    with open(count_file, "w") as f:
+        json.dump({c["name"]: c["launches"] for c in classes if c["launches"]}, f)
+    print("counted", classes)
+    sys.exit(0)
 for _ in range(reps):
     if op == "enter":
         y = tree.enter(x)
