@@ -17,6 +17,7 @@
 #include <vector>
 #include <mutex>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include "kernels.h"
 #include "host_curve.h"
@@ -116,10 +117,10 @@ public:
         N_ = host_.n; L_ = ilog2(N_); device_ = device;
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
-        // arena per tree of m leaves: 6m elements of reference tables (xnn, z*) + 10m table constants of the hot path
+        // arena per tree of m leaves: 6m elements of reference tables (xnn, z*) + 11m table constants of the hot path
         // (F::telem each); + f (2N) + den coefficients
         size_t total = 2 * N_ + 64;
-        for (unsigned l = 0; l <= L_; ++l) total += (6 + 10 * kTeElems) * ((size_t)1 << l) + 1024;
+        for (unsigned l = 0; l <= L_; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         f_ = take(2 * N_);
@@ -199,6 +200,8 @@ public:
         int tgt = 1 - srcpar;
         unsigned tz = (unsigned)__builtin_ctzll((unsigned long long)total);   // tiles must divide count*e
         unsigned log_tile = tz < kLogTileMax ? tz : kLogTileMax;
+        const bool small = small_launch(total) && !ef_small_off_;           // latency regime: 4x smaller tiles, 4x as many workgroups
+        if (small && log_tile > kLogLowSmall) log_tile = kLogLowSmall;
         unsigned k_first = le > log_tile ? le - log_tile : 0;                 // first stage with 2h <= tile
         if (k_first < k_begin) k_first = k_begin;
         if (ef && k_first == 0 && le + 1 > log_tile) log_tile = le + 1;       // ST_ENTER wants whole [U | V] blocks in the tile (64 KiB at e = tile)
@@ -207,6 +210,7 @@ public:
         Pass passes[2 * 8 + 1]; int np = 0;
         if (k_first > k_begin) {                                              // balanced groups of <= kColStages stages
             unsigned log_ct0 = tz < kLogColTileMax ? tz : kLogColTileMax;
+            if (small && log_ct0 > kLogLowSmall) log_ct0 = kLogLowSmall;
             unsigned rmax = kColStages < log_ct0 - 2 ? kColStages : log_ct0 - 2;    // keep rows >= 4 elements (128 B)
             if (rmax < 1) rmax = 1;
             unsigned ncol = k_first - k_begin, ngrp = (ncol + rmax - 1) / rmax;
@@ -227,17 +231,19 @@ public:
                 const Pass& P = passes[pi];
                 d = io; d.src = buf; d.dst = buf; d.ld_mode = next_ld->ld_mode; d.ld_tbl = next_ld->ld_tbl;
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;
+                if (small && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
                 ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R), s,
-                             d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
+                             d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c, T.c0t[tgt]);
                 return true;
             }
             if (last && ef && passes[pi].kind == 2) {
                 // last recombine group (stages kb..0) + the ENTER level's combine, two vectors per workgroup
                 const Pass& P = passes[pi];
                 unsigned log_ct = le < kLogColTileMax ? le : kLogColTileMax;
+                if (small && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
                 unsigned R = P.kb + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + ef->extra;
@@ -264,26 +270,27 @@ public:
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
                 if (log_tile == kLogTileMax + 1 && (sizeof(E) == 4 || ECFFT_CT_ALL))
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
                 else if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
                 else
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, 0>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
             } else {
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;           // column tiles may be larger than row tiles
+                if (small && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
                 const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
                 dim3 grid((unsigned)(total >> log_ct)); size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R);
                 if (P.kind == 0) {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
+                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar]);
+                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar]);
                 } else {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
+                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr);
+                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr);
                 }
             }
         }
@@ -525,13 +532,18 @@ public:
         E* bufA = base; E* bufB = base + nt; E* work = base + 2 * nt;
         const E* src = in;
         unsigned l0 = l_begin;
-        if (l_begin == 1 && l_end >= kLogLow) {
-            // levels 1..kLogLow: one launch, one HBM round trip (k_enter_low)
-            E* dst = (l_end == kLogLow && out != in) ? out : bufA;
-            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += enter_level_alg_bytes(nt, l);
-            ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(nt >> kLogLow)), dim3(kBlockLds),
-                         2 * (sizeof(E) << kLogLow), s, dst, src, (const Tree*)d_trees_);
-            src = dst; l0 = kLogLow + 1;
+        const unsigned ll = log_low_for(nt);
+        if (l_begin == 1 && l_end >= ll) {
+            // levels 1..ll: one launch, one HBM round trip (k_enter_low)
+            E* dst = (l_end == ll && out != in) ? out : bufA;
+            double bytes = 0; for (unsigned l = 1; l <= ll; ++l) bytes += enter_level_alg_bytes(nt, l);
+            if (ll == kLogLow)
+                ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLow>), dim3((unsigned)(nt >> kLogLow)), dim3(kBlockLds),
+                             2 * (sizeof(E) << kLogLow), s, dst, src, (const Tree*)d_trees_);
+            else
+                ECFFT_LAUNCH(KC_FUSED_ENTER, bytes, (k_enter_low<F, (int)kLogLowSmall, 2 * (int)kBlockLowSmall>), dim3((unsigned)(nt >> kLogLowSmall)), dim3(2 * kBlockLowSmall),
+                             2 * (sizeof(E) << kLogLowSmall), s, dst, src, (const Tree*)d_trees_);
+            src = dst; l0 = ll + 1;
         }
         for (unsigned l = l0; l <= l_end; ++l) {
             const Tree& T = trees_[l];
@@ -565,6 +577,13 @@ public:
     static constexpr unsigned kSplitDepth = ECFFT_SPLIT_DEPTH;      // recursion depth of the halving (2^depth concurrent streams)
     static constexpr int kMaxSides = 7;
     static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)
+    // SMALL launches (fewer tiles than CUs) are latency bound: tools/ubench/sweep.hip shows that ONE 512-thread workgroup
+    // already saturates its CU's integer VALUs (a sweep of 512 pairs = 4 multiplies per SIMD, ~3900 cycles), so the only way
+    // to shorten a sweep is to spread a tile's pairs over more CUs.  For 32-byte fields launches with < kSmallTiles tiles of
+    // the default size use 4x smaller tiles: 256 elements, 128-thread low-level kernels, one wave per SIMD.
+    static constexpr unsigned kLogLowSmall = 8, kBlockLowSmall = 128, kSmallTiles = 256;
+    static bool small_launch(size_t total) { return sizeof(E) == 32 && (total >> kLogLow) < kSmallTiles && total >= ((size_t)1 << kLogLowSmall); }
+    static unsigned log_low_for(size_t total) { return small_launch(total) ? kLogLowSmall : kLogLow; }
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
     bool exit(const E* in, E* out, size_t n1, size_t count, hipStream_t s) {
@@ -599,7 +618,8 @@ public:
         E* bufA = base; E* bufB = base + n; E* G = base + 2 * n; E* H = G + n / 2;
         const E* cur = in;
         size_t nh = n / 2;
-        unsigned l_stop = (l_to == 1 && l_from >= kLogLow) ? kLogLow : l_to - 1;      // levels l_stop..1 run fused in k_exit_low
+        const unsigned ll = log_low_for(n);
+        unsigned l_stop = (l_to == 1 && l_from >= ll) ? ll : l_to - 1;      // levels l_stop..1 run fused in k_exit_low
         for (unsigned l = l_from; l > l_stop; --l) {
             const Tree& T = trees_[l];
             E* dst = (l == l_to && out != in) ? out : (cur == bufA ? bufB : bufA);
@@ -628,11 +648,15 @@ public:
             extend_core(l, io4, G, nh, 1, s, 0.0, se * (1.5 * n + 0.5 * ee), 0, nullptr, f3);
             cur = dst;
         }
-        if (l_to == 1 && l_from >= kLogLow) {
+        if (l_to == 1 && l_from >= ll) {
             E* dst = out != in ? out : (cur == bufA ? bufB : bufA);
-            double bytes = 0; for (unsigned l = 1; l <= kLogLow; ++l) bytes += exit_level_alg_bytes(n, l);
-            ECFFT_LAUNCH(KC_FUSED_EXIT, bytes, (k_exit_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
-                         2 * (sizeof(E) << kLogLow), s, dst, cur, (const Tree*)d_trees_);
+            double bytes = 0; for (unsigned l = 1; l <= ll; ++l) bytes += exit_level_alg_bytes(n, l);
+            if (ll == kLogLow)
+                ECFFT_LAUNCH(KC_FUSED_EXIT, bytes, (k_exit_low<F, (int)kLogLow>), dim3((unsigned)(n >> kLogLow)), dim3(kBlockLds),
+                             2 * (sizeof(E) << kLogLow), s, dst, cur, (const Tree*)d_trees_);
+            else
+                ECFFT_LAUNCH(KC_FUSED_EXIT, bytes, (k_exit_low<F, (int)kLogLowSmall, (int)kBlockLowSmall>), dim3((unsigned)(n >> kLogLowSmall)), dim3(kBlockLowSmall),
+                             2 * (sizeof(E) << kLogLowSmall), s, dst, cur, (const Tree*)d_trees_);
             cur = dst;
         }
         if (cur != out) (void)hipMemcpyAsync(out, cur, n * sizeof(E), hipMemcpyDeviceToDevice, s);
@@ -985,6 +1009,13 @@ private:
             }
             T.inner[sg] = to_tables(in, 2, s);
         }
+        for (int sg = 0; sg < 2; ++sg) {   // c0t = np0 * dinv (pair-split decompose, kernels.h lds_extend_core)
+            E* c0 = temp(es);
+            if (e > 1) { const E *n0 = hnp0[sg], *di = hdinv[sg]; foreach_n(s, e - 1, [=] __device__(size_t g) { c0[g] = F::mul(n0[g], di[g]); }); }
+            else (void)hipMemsetAsync(c0, 0, sizeof(E), s);
+            if (e > 1) (void)hipMemsetAsync(c0 + (e - 1), 0, sizeof(E), s);
+            T.c0t[sg] = to_tables(c0, es, s);
+        }
         for (int sg = 0; sg < 2; ++sg) {
             if (e == 1) {   // no butterfly stage: the (never read) stage tables still get defined contents
                 (void)hipMemsetAsync(hp0[sg], 0, sizeof(E), s); (void)hipMemsetAsync(hp1[sg], 0, sizeof(E), s);
@@ -1105,6 +1136,7 @@ private:
     mutable Profiler prof_;
     hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
+    bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };
 
 }  // namespace ecfft

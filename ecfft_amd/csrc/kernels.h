@@ -315,11 +315,29 @@ constexpr int kBlockRow = ECFFT_BLOCK_ROW;   // ... of the row kernel (k_stages_
 // their partners and their table entries are then contiguous and 16-byte aligned): 4x fewer memory instructions and
 // index computations.  No trailing barrier.
 // ---------------------------------------------------------------------------------------------
+// PAIR-SPLIT form (32-byte fields, sweeps with at most BLK/2 pairs — the small tiles of latency-bound launches): threads
+// [0, npairs) produce the LOW output of every pair, threads [npairs, 2*npairs) the HIGH one, ONE multiply each (decompose through
+// tc = np0*dinv, which makes its two products independent), so a sweep costs one multiply of latency instead of two dependent
+// ones and twice as many SIMDs work.  Both roles read (a, b); a barrier separates those reads from the in-place writes.
 template <class F, bool DEC, int BLK = kBlockLds>
 __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
-                                            uint32_t lh, uint32_t npairs, uint32_t tid) {
+                                            uint32_t lh, uint32_t npairs, uint32_t tid, const typename F::telem* __restrict__ tc = nullptr) {
     using E = typename F::elem;
     const uint32_t h = 1u << lh;
+    if constexpr (sizeof(E) == 32) {
+        if (2 * npairs <= (uint32_t)BLK && (!DEC || tc)) {
+            const bool act = tid < 2 * npairs, hi = tid >= npairs;
+            const uint32_t g = hi ? tid - npairs : tid, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+            E x, y; typename F::telem t;
+            if (act) { x = a_[idx]; y = a_[idx + h]; t = DEC ? (hi ? tb[i] : tc[i]) : (hi ? tb[i] : ta[i]); }
+            __syncthreads();
+            if (act) {
+                if (DEC) { const E d = F::sub(y, x); if (hi) a_[idx + h] = F::tmul(t, d); else a_[idx] = F::tmul_add(t, d, x); }
+                else a_[idx + (hi ? h : 0)] = F::tmul_add(t, y, x);
+            }
+            return;
+        }
+    }
     if constexpr (sizeof(E) == 4) {
         if (lh >= 2 && (npairs & 3u) == 0) {
             for (uint32_t g4 = tid; g4 < (npairs >> 2); g4 += BLK) {
@@ -503,7 +521,8 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                                                            const typename F::telem* __restrict__ p0,
                                                            const typename F::telem* __restrict__ p1,
                                                            const typename F::telem* __restrict__ inner,
-                                                           uint32_t log_e, uint32_t k_first, uint32_t log_tile) {
+                                                           uint32_t log_e, uint32_t k_first, uint32_t log_tile,
+                                                           const typename F::telem* __restrict__ c0t) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -533,10 +552,18 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     for (uint32_t k = k_first; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid);
+        stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid, c0t ? c0t + (e - 2 * (size_t)h) : nullptr);
         __syncthreads();
     }
     if (log_e > 0) {
+        if (sizeof(E) == 32 && 2 * npairs <= (uint32_t)kBlockRow) {        // pair-split merged innermost stage
+            const bool act = tid < 2 * npairs, hi = tid >= npairs;
+            const uint32_t g = hi ? tid - npairs : tid;
+            E a, b; typename F::telem c;
+            if (act) { a = tile[2 * g]; b = tile[2 * g + 1]; c = inner[hi ? 1 : 0]; }
+            __syncthreads();
+            if (act) tile[2 * g + (hi ? 1 : 0)] = F::tmul_add(c, F::sub(b, a), a);
+        } else {
         const typename F::telem c0 = inner[0], c1 = inner[1];
 #pragma unroll
         for (uint32_t g = tid; g < npairs; g += kBlockRow) {
@@ -544,6 +571,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
             E d = F::sub(b, a);
             tile[2 * g] = F::tmul_add(c0, d, a);
             tile[2 * g + 1] = F::tmul_add(c1, d, a);
+        }
         }
         __syncthreads();
     }
@@ -593,9 +621,27 @@ __host__ __device__ constexpr uint32_t col_row_stride(uint32_t C) { return C + (
 // column-tile variant of stage_sweep: pair (row r, column cc) with partner d rows below; table entry ((r mod d) << log_hs) + c0 + cc
 template <class F, bool DEC>
 __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const typename F::telem* __restrict__ pa, const typename F::telem* __restrict__ pb,
-                                                uint32_t sft, uint32_t log_c, uint32_t log_hs, size_t c0, uint32_t npairs, uint32_t tid) {
+                                                uint32_t sft, uint32_t log_c, uint32_t log_hs, size_t c0, uint32_t npairs, uint32_t tid,
+                                                const typename F::telem* __restrict__ pc = nullptr) {
     using E = typename F::elem;
     const uint32_t C = 1u << log_c, d = 1u << sft;
+    if constexpr (sizeof(E) == 32) {
+        if (2 * npairs <= (uint32_t)kBlockLds && (!DEC || pc)) {          // pair-split form, see stage_sweep
+            const bool act = tid < 2 * npairs, hi = tid >= npairs;
+            const uint32_t g = hi ? tid - npairs : tid, cc = g & (C - 1), pr = g >> log_c;
+            const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
+            const size_t i = ((size_t)(r & (d - 1)) << log_hs) + c0 + cc;
+            const uint32_t RS = col_row_stride<E>(C), lo = r * RS + cc, up = lo + d * RS;
+            E x, y; typename F::telem t;
+            if (act) { x = tile[lo]; y = tile[up]; t = DEC ? (hi ? pb[i] : pc[i]) : (hi ? pb[i] : pa[i]); }
+            __syncthreads();
+            if (act) {
+                if (DEC) { const E dd = F::sub(y, x); if (hi) tile[up] = F::tmul(t, dd); else tile[lo] = F::tmul_add(t, dd, x); }
+                else tile[hi ? up : lo] = F::tmul_add(t, y, x);
+            }
+            return;
+        }
+    }
     if constexpr (sizeof(E) == 4) {
         if (log_c >= 2) {
             for (uint32_t g4 = tid; g4 < (npairs >> 2); g4 += kBlockLds) {
@@ -635,7 +681,8 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
 // trip, table constants requested before the barrier); everything else sweeps one stage at a time.  Ends with a barrier.
 template <class F, bool DEC>
 __device__ __forceinline__ void col_stages(typename F::elem* tile, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
-                                           uint32_t R, uint32_t log_c, uint32_t log_hs, size_t c0, size_t e, uint32_t tid, uint32_t halves = 1) {
+                                           uint32_t R, uint32_t log_c, uint32_t log_hs, size_t c0, size_t e, uint32_t tid, uint32_t halves = 1,
+                                           const typename F::telem* __restrict__ tc = nullptr) {
     // halves = 2: two such tiles back to back in LDS that use the same table entries (k_stages_col_enter)
     using E = typename F::elem;
     const uint32_t C = 1u << log_c, T = C << R;
@@ -670,7 +717,7 @@ __device__ __forceinline__ void col_stages(typename F::elem* tile, const typenam
     for (uint32_t st = 0; st < R; ++st) {
         const uint32_t sft = DEC ? R - 1 - st : st;
         const size_t h = hs << sft;
-        col_stage_sweep<F, DEC>(tile, ta + (e - 2 * h), tb + (e - 2 * h), sft, log_c, log_hs, c0, (halves * T) >> 1, tid);   // pairs never cross a tile (row distance < 2^R)
+        col_stage_sweep<F, DEC>(tile, ta + (e - 2 * h), tb + (e - 2 * h), sft, log_c, log_hs, c0, (halves * T) >> 1, tid, tc ? tc + (e - 2 * h) : nullptr);   // pairs never cross a tile (row distance < 2^R)
         __syncthreads();
     }
 }
@@ -687,7 +734,8 @@ template <class F, bool DECOMPOSE, int LOG_TILE_CT>     // LOG_TILE_CT > 0: log2
 __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDesc<F> io,
                                                            const typename F::telem* __restrict__ ta,   // np0 | p0
                                                            const typename F::telem* __restrict__ tb,   // dinv | p1
-                                                           uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+                                                           uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c,
+                                                           const typename F::telem* __restrict__ tc) {  // np0*dinv (pair-split decompose) | unused
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -713,7 +761,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
         }
     }
     __syncthreads();
-    col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid);
+    col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1, DECOMPOSE ? tc : nullptr);
     if constexpr (kFast) { if (vio) { vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid); return; } }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
@@ -733,7 +781,8 @@ template <class F>
 __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(IoDesc<F> io,
                                                                const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
                                                                const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
-                                                               uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+                                                               uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c,
+                                                               const typename F::telem* __restrict__ c0t) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -759,7 +808,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
             col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid);
             vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
             __syncthreads();
-            col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid);
+            col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1, c0t);
             vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid);
             return;
         }
@@ -775,7 +824,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
         { const uint32_t q = r * col_row_stride<E>(C) + cc; tile[q] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[q]); }
     }
     __syncthreads();
-    col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid);
+    col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1, c0t);
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io.dst[B + ((size_t)r << log_hs) + cc] = F::canon(tile[r * col_row_stride<E>(C) + cc]);
@@ -870,31 +919,71 @@ struct LevelTables {
     TE *w[2], *winv[2];
     TE *xe, *w1x, *A1, *B1, *NB2, *C1, *D1, *xie;
     TE *inner[2];   // inner[srcpar] = {c0, c1}: the merged innermost (h = 1) decompose+recombine stage, out_j = a + c_j*(b - a)
+    TE *c0t[2];     // c0t[s] = np0[s]*dinv[s]: decompose as two INDEPENDENT multiplies, q0 = a + c0t*(b - a), q1 = dinv*(b - a) (pair-split sweeps)
     E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
 };
 
 // every stage (decompose then recombine) of EXTEND on `len` LDS elements = len/e vectors of length e;
 // srcpar = parity of the source moiety.  Ends with a barrier.
-template <class F>
+template <class F, int BLK = kBlockLds>
 __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<F>& T, int srcpar) {
     using E = typename F::elem;
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
+    if constexpr (sizeof(E) == 32) {
+        if (len == BLK) {
+            // PAIR-SPLIT sweeps (k_exit_low: half as many pairs as threads).  One butterfly = two multiplies; with one pair per
+            // thread half the workgroup idles and every sweep costs two dependent 169-instruction multiplies.  Here waves 0..3
+            // produce the LOW output of every pair and waves 4..7 the HIGH one, one multiply each (decompose through the extra
+            // table c0t = np0*dinv, which makes its two products independent): a sweep costs one multiply of latency and all
+            // eight waves issue.  Both roles read (a, b); a barrier separates the reads from the in-place writes.
+            const uint32_t g = tid & (npairs - 1);
+            const bool hi = tid >= npairs;                                  // wave-uniform: npairs is a multiple of 64
+            const uint32_t k_inner = log_e ? log_e - 1 : 0;
+            for (uint32_t k = 0; k < k_inner; ++k) {
+                const uint32_t lh = log_e - k - 1, h = 1u << lh, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+                const size_t off = e - 2 * (size_t)h + i;
+                const typename F::telem t = hi ? T.dinv[srcpar][off] : T.c0t[srcpar][off];
+                const E x = a[idx], y = a[idx + h];
+                __syncthreads();
+                const E d = F::sub(y, x);
+                if (hi) a[idx + h] = F::tmul(t, d); else a[idx] = F::tmul_add(t, d, x);
+                __syncthreads();
+            }
+            if (log_e > 0) {
+                const typename F::telem t = T.inner[srcpar][hi ? 1 : 0];
+                const E x = a[2 * g], y = a[2 * g + 1];
+                __syncthreads();
+                a[2 * g + (hi ? 1 : 0)] = F::tmul_add(t, F::sub(y, x), x);
+                __syncthreads();
+            }
+            for (uint32_t k = k_inner; k-- > 0;) {
+                const uint32_t lh = log_e - k - 1, h = 1u << lh, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+                const size_t off = e - 2 * (size_t)h + i;
+                const typename F::telem t = hi ? T.p1[tgt][off] : T.p0[tgt][off];
+                const E x = a[idx], y = a[idx + h];
+                __syncthreads();
+                a[idx + (hi ? h : 0)] = F::tmul_add(t, y, x);
+                __syncthreads();
+            }
+            return;
+        }
+    }
     if constexpr (sizeof(E) == 4) {
         // callers have published `a` with a barrier; the engine starts with one of its own and ends with one
-        if (len == kBlockLds * 16) { lds_extend_fast<F, 16, kBlockLds>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
-        if (len == kBlockLds * 8) { lds_extend_fast<F, 8, kBlockLds>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
+        if (len == BLK * 16) { lds_extend_fast<F, 16, BLK>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
+        if (len == BLK * 8) { lds_extend_fast<F, 8, BLK>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
     }
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     for (uint32_t k = 0; k < k_inner; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        stage_sweep<F, true>(a, T.np0[srcpar] + (e - 2 * (size_t)h), T.dinv[srcpar] + (e - 2 * (size_t)h), lh, npairs, tid);
+        stage_sweep<F, true, BLK>(a, T.np0[srcpar] + (e - 2 * (size_t)h), T.dinv[srcpar] + (e - 2 * (size_t)h), lh, npairs, tid, T.c0t[srcpar] + (e - 2 * (size_t)h));
         __syncthreads();
     }
     if (log_e > 0) {                                    // merged innermost stage pair (h = 1)
         const typename F::telem c0 = T.inner[srcpar][0], c1 = T.inner[srcpar][1];
-        for (uint32_t g = tid; g < npairs; g += kBlockLds) {
+        for (uint32_t g = tid; g < npairs; g += BLK) {
             E x = a[2 * g], y = a[2 * g + 1];
             E d = F::sub(y, x);
             a[2 * g] = F::tmul_add(c0, d, x);
@@ -904,39 +993,40 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     }
     for (uint32_t k = k_inner; k-- > 0;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
-        stage_sweep<F, false>(a, T.p0[tgt] + (e - 2 * (size_t)h), T.p1[tgt] + (e - 2 * (size_t)h), lh, npairs, tid);
+        stage_sweep<F, false, BLK>(a, T.p0[tgt] + (e - 2 * (size_t)h), T.p1[tgt] + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
     }
 }
 
 // ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
-template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+template <class F, int LOG_TILE, int BLK = kBlockLds>
+__global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                           const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, npairs = T >> 1;
-    constexpr int PAIRS = (int)(npairs / kBlockLds);     // compile-time trip counts keep ev/od in registers
-    static_assert(PAIRS >= 1 && npairs % kBlockLds == 0, "tile too small for the workgroup");
+    constexpr bool kRoles = npairs * 2 == (uint32_t)BLK;    // latency variant: two threads per pair (one output each)
+    constexpr int PAIRS = kRoles ? 1 : (int)(npairs / BLK);     // compile-time trip counts keep ev/od in registers
+    static_assert(kRoles || (npairs >= (uint32_t)BLK && npairs % BLK == 0), "tile too small for the workgroup");
     const uint32_t tid = threadIdx.x;
     E* cur = reinterpret_cast<E*>(ecfft_smem);
     E* work = cur + T;
     const size_t base = (size_t)blockIdx.x << log_tile;
-    constexpr bool kQuad = sizeof(E) == 4 && T % (4 * kBlockLds) == 0;     // 4-byte fields: quad-vectorised, loads-first pointwise steps
+    constexpr bool kQuad = sizeof(E) == 4 && T % (4 * BLK) == 0;     // 4-byte fields: quad-vectorised, loads-first pointwise steps
     bool qio = false;                                                      // user pointers may be only element-aligned
     if constexpr (kQuad) qio = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if constexpr (kQuad) {
         if (qio) {
-            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            constexpr int NQ = (int)(T / (4 * BLK));
             Quad d[NQ];
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * kBlockLds));
+            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * BLK));
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * BLK), d[c]);
         }
     }
     if (!qio) {
-        for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+        for (uint32_t j = tid; j < T; j += BLK) cur[j] = src[base + j];
     }
     __syncthreads();
     for (uint32_t l = 1; l <= log_tile; ++l) {
@@ -944,28 +1034,28 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
         const uint32_t le = l - 1, e = 1u << le;
         if constexpr (kQuad) {
             if (le >= 2) {
-                constexpr int NQ = (int)(T / (4 * kBlockLds)), NP = NQ / 2;
+                constexpr int NQ = (int)(T / (4 * BLK)), NP = NQ / 2;
                 {
                     Quad x[NQ], t[NQ];
                     const typename F::telem* wi = L.winv[0];
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c) { const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds); t[c] = ldq(wi + (j & (e - 1))); x[c] = ldq(cur + j); }
+                    for (int c = 0; c < NQ; ++c) { const uint32_t j = 4u * (tid + (uint32_t)c * BLK); t[c] = ldq(wi + (j & (e - 1))); x[c] = ldq(cur + j); }
 #pragma unroll
                     for (int c = 0; c < NQ; ++c) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) x[c].v[k] = F::tmul(t[c].v[k], x[c].v[k]);
-                        stq(work + 4u * (tid + (uint32_t)c * kBlockLds), x[c]);
+                        stq(work + 4u * (tid + (uint32_t)c * BLK), x[c]);
                     }
                 }
                 __syncthreads();
-                lds_extend_core<F>(work, T, le, L, 0);
+                lds_extend_core<F, BLK>(work, T, le, L, 0);
                 Quad lo[NP], hi[NP];
                 {
                     Quad u0[NP], v0[NP], U1[NP], V1[NP], tx[NP], tw[NP], twx[NP];
                     const typename F::telem *xe = L.xe, *w1 = L.w[1], *w1x = L.w1x;
 #pragma unroll
                     for (int c = 0; c < NP; ++c) {
-                        const uint32_t g = 4u * (tid + (uint32_t)c * kBlockLds), i = g & (e - 1), bb = (g >> le) << l;
+                        const uint32_t g = 4u * (tid + (uint32_t)c * BLK), i = g & (e - 1), bb = (g >> le) << l;
                         tx[c] = ldq(xe + i); tw[c] = ldq(w1 + i); twx[c] = ldq(w1x + i);
                         u0[c] = ldq(cur + bb + i); v0[c] = ldq(cur + bb + e + i); U1[c] = ldq(work + bb + i); V1[c] = ldq(work + bb + e + i);
                     }
@@ -981,22 +1071,33 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
                 __syncthreads();
 #pragma unroll
                 for (int c = 0; c < NP; ++c) {
-                    const uint32_t g = 4u * (tid + (uint32_t)c * kBlockLds), i = g & (e - 1), bb = (g >> le) << l;
+                    const uint32_t g = 4u * (tid + (uint32_t)c * BLK), i = g & (e - 1), bb = (g >> le) << l;
                     stq(cur + bb + 2 * i, lo[c]); stq(cur + bb + 2 * i + 4, hi[c]);
                 }
                 __syncthreads();
                 continue;
             }
         }
-        for (uint32_t j = tid; j < T; j += kBlockLds) work[j] = F::tmul(L.winv[0][j & (e - 1)], cur[j]);
+        for (uint32_t j = tid; j < T; j += BLK) work[j] = F::tmul(L.winv[0][j & (e - 1)], cur[j]);
         __syncthreads();
-        lds_extend_core<F>(work, T, le, L, 0);
+        lds_extend_core<F, BLK>(work, T, le, L, 0);
         // combine (:155-159): block [u0|v0] + extended [U1|V1] -> interleaved evaluations; results are held in
         // registers across the barrier because the interleaving store overwrites other threads' inputs
+        if constexpr (kRoles) {
+            const bool hi = tid >= npairs;
+            const uint32_t g = hi ? tid - npairs : tid, i = g & (e - 1), bb = (g >> le) << l;
+            E r;
+            if (!hi) r = F::tmul_add(L.xe[i], cur[bb + e + i], cur[bb + i]);
+            else r = F::tmul_add(L.w1x[i], work[bb + e + i], F::tmul(L.w[1][i], work[bb + i]));
+            __syncthreads();
+            cur[bb + 2 * i + (hi ? 1 : 0)] = r;
+            __syncthreads();
+            continue;
+        }
         E ev[PAIRS], od[PAIRS];
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
-            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1), bb = (g >> le) << l;
             E u0 = cur[bb + i], v0 = cur[bb + e + i], U1 = work[bb + i], V1 = work[bb + e + i];
             ev[c] = F::tmul_add(L.xe[i], v0, u0);
             od[c] = F::tmul_add(L.w1x[i], V1, F::tmul(L.w[1][i], U1));
@@ -1004,57 +1105,57 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_enter_low(typena
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
-            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1), bb = (g >> le) << l;
             cur[bb + 2 * i] = ev[c]; cur[bb + 2 * i + 1] = od[c];
         }
         __syncthreads();
     }
     if constexpr (kQuad) {
         if (qio) {
-            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            constexpr int NQ = (int)(T / (4 * BLK));
 #pragma unroll
             for (int c = 0; c < NQ; ++c) {
-                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * kBlockLds));
+                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * BLK));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) q.v[k] = F::canon(q.v[k]);
-                stq(dst + base + 4u * (tid + (uint32_t)c * kBlockLds), q);
+                stq(dst + base + 4u * (tid + (uint32_t)c * BLK), q);
             }
             return;
         }
     }
-    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
+    for (uint32_t j = tid; j < T; j += BLK) dst[base + j] = F::canon(cur[j]);
 }
 
 // EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
 // DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
-template <class F, int LOG_TILE>
-__global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+template <class F, int LOG_TILE, int BLK = kBlockLds>
+__global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                          const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     constexpr uint32_t log_tile = LOG_TILE, T = 1u << LOG_TILE, nh = T >> 1;
-    constexpr int PAIRS = (int)(nh / kBlockLds);
-    static_assert(PAIRS >= 1 && nh % kBlockLds == 0, "tile too small for the workgroup");
+    constexpr int PAIRS = (int)(nh / BLK);
+    static_assert(PAIRS >= 1 && nh % BLK == 0, "tile too small for the workgroup");
     const uint32_t tid = threadIdx.x;
     E* cur = reinterpret_cast<E*>(ecfft_smem);
     E* G = cur + T;
     E* H = G + nh;
     const size_t base = (size_t)blockIdx.x << log_tile;
-    constexpr bool kQuad = sizeof(E) == 4 && nh % (4 * kBlockLds) == 0;
+    constexpr bool kQuad = sizeof(E) == 4 && nh % (4 * BLK) == 0;
     bool qio = false;                                                      // user pointers may be only element-aligned
     if constexpr (kQuad) qio = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if constexpr (kQuad) {
         if (qio) {
-            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            constexpr int NQ = (int)(T / (4 * BLK));
             Quad d[NQ];
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * kBlockLds));
+            for (int c = 0; c < NQ; ++c) d[c] = ldq(src + base + 4u * (tid + (uint32_t)c * BLK));
 #pragma unroll
-            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+            for (int c = 0; c < NQ; ++c) stq(cur + 4u * (tid + (uint32_t)c * BLK), d[c]);
         }
     }
     if (!qio) {
-        for (uint32_t j = tid; j < T; j += kBlockLds) cur[j] = src[base + j];
+        for (uint32_t j = tid; j < T; j += BLK) cur[j] = src[base + j];
     }
     __syncthreads();
     for (uint32_t l = log_tile; l >= 1; --l) {
@@ -1063,8 +1164,8 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
         if constexpr (kQuad) {
             if (le >= 2) {
                 // the level's five pointwise steps on quads of the pair index g (loads first), the four EXTEND cores between them
-                constexpr int NP = (int)(nh / (4 * kBlockLds));
-                auto gq = [=](int c) { return 4u * (tid + (uint32_t)c * kBlockLds); };
+                constexpr int NP = (int)(nh / (4 * BLK));
+                auto gq = [=](int c) { return 4u * (tid + (uint32_t)c * BLK); };
                 auto tq = [=](const typename F::telem* t, int c) { return ldq(t + (gq(c) & (e - 1))); };
                 auto evenq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.x, a.z, b.x, b.z}}; };
                 auto oddq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.y, a.w, b.y, b.w}}; };
@@ -1080,7 +1181,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
                     }
                 }
                 __syncthreads();
-                lds_extend_core<F>(G, nh, le, L, 0);
+                lds_extend_core<F, BLK>(G, nh, le, L, 0);
                 {
                     Quad ta[NP], tb[NP], x[NP], y[NP];
 #pragma unroll
@@ -1093,7 +1194,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
                     }
                 }
                 __syncthreads();
-                lds_extend_core<F>(G, nh, le, L, 1);
+                lds_extend_core<F, BLK>(G, nh, le, L, 1);
                 {
                     Quad t[NP], x[NP];
 #pragma unroll
@@ -1106,7 +1207,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
                     }
                 }
                 __syncthreads();
-                lds_extend_core<F>(G, nh, le, L, 0);
+                lds_extend_core<F, BLK>(G, nh, le, L, 0);
                 {
                     Quad ta[NP], tb[NP], x[NP], y[NP];
 #pragma unroll
@@ -1119,7 +1220,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
                     }
                 }
                 __syncthreads();
-                lds_extend_core<F>(G, nh, le, L, 1);
+                lds_extend_core<F, BLK>(G, nh, le, L, 1);
                 Quad uq[NP], vq[NP];
                 {
                     Quad ta[NP], tb[NP], x[NP], y[NP];
@@ -1140,54 +1241,54 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_exit_low(typenam
                 continue;
             }
         }
-        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::tmul(L.A1[g & (e - 1)], cur[2 * g]);
+        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(L.A1[g & (e - 1)], cur[2 * g]);
         __syncthreads();
-        lds_extend_core<F>(G, nh, le, L, 0);
-        for (uint32_t g = tid; g < nh; g += kBlockLds) {
+        lds_extend_core<F, BLK>(G, nh, le, L, 0);
+        for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
             E r = F::tmul_add(L.NB2[i], G[g], F::tmul(L.B1[i], cur[2 * g + 1]));
             G[g] = r; H[g] = r;
         }
         __syncthreads();
-        lds_extend_core<F>(G, nh, le, L, 1);
-        for (uint32_t g = tid; g < nh; g += kBlockLds) G[g] = F::tmul(L.C1[g & (e - 1)], G[g]);
+        lds_extend_core<F, BLK>(G, nh, le, L, 1);
+        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(L.C1[g & (e - 1)], G[g]);
         __syncthreads();
-        lds_extend_core<F>(G, nh, le, L, 0);
-        for (uint32_t g = tid; g < nh; g += kBlockLds) {
+        lds_extend_core<F, BLK>(G, nh, le, L, 0);
+        for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
             G[g] = F::tmul_add(L.NB2[i], G[g], F::tmul(L.D1[i], H[g]));
         }
         __syncthreads();
-        lds_extend_core<F>(G, nh, le, L, 1);
+        lds_extend_core<F, BLK>(G, nh, le, L, 1);
         E u[PAIRS], v[PAIRS];
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
-            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1);
+            uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1);
             u[c] = F::tmul(L.w[0][i], G[g]);
             v[c] = F::tmul(L.xie[i], F::sub(cur[2 * g], u[c]));
         }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
-            uint32_t g = tid + (uint32_t)c * kBlockLds, i = g & (e - 1), bb = (g >> le) << l;
+            uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1), bb = (g >> le) << l;
             cur[bb + i] = u[c]; cur[bb + e + i] = v[c];
         }
         __syncthreads();
     }
     if constexpr (kQuad) {
         if (qio) {
-            constexpr int NQ = (int)(T / (4 * kBlockLds));
+            constexpr int NQ = (int)(T / (4 * BLK));
 #pragma unroll
             for (int c = 0; c < NQ; ++c) {
-                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * kBlockLds));
+                Quad q = ldq(cur + 4u * (tid + (uint32_t)c * BLK));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) q.v[k] = F::canon(q.v[k]);
-                stq(dst + base + 4u * (tid + (uint32_t)c * kBlockLds), q);
+                stq(dst + base + 4u * (tid + (uint32_t)c * BLK), q);
             }
             return;
         }
     }
-    for (uint32_t j = tid; j < T; j += kBlockLds) dst[base + j] = F::canon(cur[j]);
+    for (uint32_t j = tid; j < T; j += BLK) dst[base + j] = F::canon(cur[j]);
 }
 
 // ---------------------------------------------------------------------------------------------

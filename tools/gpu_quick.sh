@@ -16,7 +16,7 @@ import json
 try:
     d=json.loads(open("gpurun_out/q/bench_$fld.json").read().strip().splitlines()[-1])
     print("$fld", "ms_per_step", round(d["ms_per_step"],3), "enter", round(d.get("enter_ms",0),3), "exit", round(d.get("exit_ms",0),3), "batched", d["batched"] and round(d["batched"]["ms_per_transform_pair"],3))
-    for k in d["roofline"]["kernels"]: print("   ", k["name"], k["launches"], round(k["ms"],2))
+    for k in d["roofline"]["per_class"]: print("   ", k["name"], k["launches_per_step"], round(k["event_ms_per_step"],3), "hbm_frac", k.get("hbm_frac"))
 except Exception as e:
     print("$fld bench failed", e); print(open("gpurun_out/q/bench_$fld.err").read()[-2000:])
 PY
