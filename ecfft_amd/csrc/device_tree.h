@@ -568,7 +568,7 @@ public:
         return sizeof(E) * (8.0 * (l - 1) * (double)n + 8.5 * (double)n + tblw_ * (32.0 * (e - 1) + 8.5 * e));
     }
 #ifndef ECFFT_SPLIT_MIN_LOG
-#define ECFFT_SPLIT_MIN_LOG 16
+#define ECFFT_SPLIT_MIN_LOG 19
 #endif
     static constexpr unsigned kSplitMinLog = ECFFT_SPLIT_MIN_LOG;   // single transforms of at least 2^this run as concurrent halves
 #ifndef ECFFT_SPLIT_DEPTH

@@ -10,7 +10,7 @@ import ecfft_amd
 from bench import synth
 field = sys.argv[1] if len(sys.argv) > 1 else "secp256k1"
 F = ecfft_amd.FIELDS[field]
-for ln in (8, 10, 11, 12, 14, 16, 17, 18):
+for ln in [int(a) for a in os.environ.get("SIZES", "8,10,11,12,14,16,17,18").split(",")]:
     n = 1 << ln
     t = F.build_fftree(n)
     h = synth(field, n, 1)
