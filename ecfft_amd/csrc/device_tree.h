@@ -235,8 +235,9 @@ public:
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
-                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> log_ct)), dim3(kBlockLds), sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R), s,
-                             d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c, T.c0t[tgt]);
+                const unsigned lv = pair_spans(total, le, P.ka, log_ct);
+                ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> (log_ct + lv))), dim3(kBlockLds), (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv, s,
+                             d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c, T.c0t[tgt], (uint32_t)lv);
                 return true;
             }
             if (last && ef && passes[pi].kind == 2) {
@@ -284,17 +285,25 @@ public:
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
                 const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
-                dim3 grid((unsigned)(total >> log_ct)); size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R);
+                const unsigned lv = ct ? pair_spans(total, le, P.ka, log_ct) : 0;
+                dim3 grid((unsigned)(total >> (log_ct + lv))); size_t lds = (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv;
                 if (P.kind == 0) {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar]);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar]);
+                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
+                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
                 } else {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr);
+                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv);
+                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv);
                 }
             }
         }
         return false;
+    }
+    // 4-byte fields, full-size column tiles: two consecutive spans (2h_ka-blocks; they read the same table entries) per workgroup
+    // when the number of spans is even and the halved grid still fills the chip twice over
+    static unsigned pair_spans(size_t total, unsigned le, unsigned ka, unsigned log_ct) {
+        if (sizeof(E) != 4 || ECFFT_COL_PAD != 0 || log_ct != kLogColTileMax) return 0;
+        const size_t nspans = total >> (le - ka);
+        return (nspans >= 2 && (nspans & 1) == 0 && (total >> (log_ct + 1)) >= 512) ? 1u : 0u;
     }
     static IoDesc<F> io_plain(const E* src, E* dst) {
         IoDesc<F> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;

@@ -391,8 +391,11 @@ __device__ __forceinline__ void bfly(typename F::elem& a, typename F::elem& b, c
 // step's LDS writes visible (after the table loads have been issued); does NOT end with one.
 template <class F, int NS, bool DEC, int NG>
 __device__ __forceinline__ void radix_step(typename F::elem* a, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
-                                           uint32_t e, const uint32_t (&pbase)[NG], uint32_t pstride, const uint32_t (&tbase)[NG], uint32_t tstride) {
-    // all table offsets are 32-bit (tables of one tree have < 2^31 entries): uniform base pointer + 32-bit lane offset
+                                           uint32_t e, const uint32_t (&pbase)[NG], uint32_t pstride, const uint32_t (&tbase)[NG], uint32_t tstride,
+                                           uint32_t halves = 1, uint32_t hstride = 0) {
+    // all table offsets are 32-bit (tables of one tree have < 2^31 entries): uniform base pointer + 32-bit lane offset.
+    // halves > 1: the same step on `halves` arrays `hstride` elements apart that use the SAME table entries (two vectors of a
+    // batched EXTEND): the constants are loaded once
     using E = typename F::elem;
     using TE = typename F::telem;
     constexpr int G = 1 << NS;
@@ -407,24 +410,27 @@ __device__ __forceinline__ void radix_step(typename F::elem* a, const typename F
         }
     }
     __syncthreads();
-    E x[NG][G];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int j = 0; j < G; ++j) x[g][j] = a[pbase[g] + (uint32_t)j * pstride];
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        const int sp = DEC ? NS - 1 - st : st;
+#pragma unroll 1
+    for (uint32_t hf = 0; hf < halves; ++hf, a += hstride) {
+        E x[NG][G];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int j = 0; j < G; ++j)
-                if (!(j & (1 << sp))) bfly<F, DEC>(x[g][j], x[g][j + (1 << sp)], t0[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))], t1[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))]);
+            for (int j = 0; j < G; ++j) x[g][j] = a[pbase[g] + (uint32_t)j * pstride];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int sp = DEC ? NS - 1 - st : st;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    if (!(j & (1 << sp))) bfly<F, DEC>(x[g][j], x[g][j + (1 << sp)], t0[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))], t1[g][(1 << sp) - 1 + (j & ((1 << sp) - 1))]);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < G; ++j) a[pbase[g] + (uint32_t)j * pstride] = x[g][j];
     }
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int j = 0; j < G; ++j) a[pbase[g] + (uint32_t)j * pstride] = x[g][j];
 }
 
 // `cnt` consecutive stages whose SMALLEST pair distance is 2^lh_low elements of a flat array (row layout: table entry =
@@ -688,7 +694,7 @@ __device__ __forceinline__ void col_stages(typename F::elem* tile, const typenam
     const uint32_t C = 1u << log_c, T = C << R;
     if constexpr (sizeof(E) == 4 && ECFFT_COL_PAD == 0) {
         if (T == kBlockLds * 16) {
-          for (uint32_t hf = 0; hf < halves; ++hf, tile += T) {
+          {
             uint32_t done = 0;
             while (done < R) {
                 const uint32_t ns = R - done >= 3 ? 3 : R - done;
@@ -703,7 +709,7 @@ __device__ __forceinline__ void col_stages(typename F::elem* tile, const typenam
                         const uint32_t rlow = rq & ((1u << slo) - 1), rb = ((rq >> slo) << (slo + NS)) | rlow;
                         pb[g] = (rb << log_c) + cc; tb0[g] = (rlow << log_hs) + (uint32_t)c0 + cc;
                     }
-                    radix_step<F, NS, DEC, NG>(tile, ta, tb, (uint32_t)e, pb, C << slo, tb0, (1u << log_hs) << slo);
+                    radix_step<F, NS, DEC, NG>(tile, ta, tb, (uint32_t)e, pb, C << slo, tb0, (1u << log_hs) << slo, halves, T);
                 };
                 if (ns == 3) run(std::integral_constant<int, 3>{}); else if (ns == 2) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 1>{});
                 done += ns;
@@ -735,7 +741,10 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
                                                            const typename F::telem* __restrict__ ta,   // np0 | p0
                                                            const typename F::telem* __restrict__ tb,   // dinv | p1
                                                            uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c,
-                                                           const typename F::telem* __restrict__ tc) {  // np0*dinv (pair-split decompose) | unused
+                                                           const typename F::telem* __restrict__ tc,    // np0*dinv (pair-split decompose) | unused
+                                                           uint32_t log_v) {  // 4-byte fast path only: 2^log_v consecutive spans per workgroup
+    // log_v = 1: two consecutive 2h_ka-spans (same column chunk) share one workgroup — every span of a stage reads the SAME table
+    // entries, so their constants are loaded once for both (halves the table traffic of the HBM-bound column passes)
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -745,14 +754,24 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
     const uint32_t log_hs = log_e - kb - 1;
     const size_t hs = (size_t)1 << log_hs;
     const uint32_t chunks_log = log_hs - log_c;                      // column chunks per 2h_ka block
-    const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+    const size_t blk = ((size_t)blockIdx.x >> chunks_log) << log_v, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t B = (blk << (log_hs + R)) + (chunk << log_c);       // position of (row 0, col 0)
     const size_t c0 = (chunk << log_c);                              // column offset inside the hs-block
     constexpr bool kFast = sizeof(E) == 4 && ECFFT_COL_PAD == 0 && LOG_TILE_CT > 0 && (1u << (LOG_TILE_CT > 0 ? LOG_TILE_CT : 0)) == kBlockLds * 16;
     bool vio = false;
     if constexpr (kFast) vio = log_c >= 2 && vio_ok<F>(io, log_e);
-    auto pos_of = [=](uint32_t j) { return B + ((size_t)(j >> log_c) << log_hs) + (j & (C - 1)); };
-    if constexpr (kFast) { if (vio) vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid); }
+    const uint32_t log_T = log_c + R;
+    auto pos_of = [=](uint32_t j) { const uint32_t jj = j & (T - 1); return B + ((size_t)(j >> log_T) << (log_hs + R)) + ((size_t)(jj >> log_c) << log_hs) + (jj & (C - 1)); };
+    if constexpr (kFast) {
+        if (log_v && !vio) return;                                   // host only pairs spans on the vector path (never taken)
+        if (vio) {
+            if (log_v) vio_load<F, 8, kBlockLds>(io, emask, tile, pos_of, tid); else vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid);
+            __syncthreads();
+            col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
+            if (log_v) vio_store<F, 8, kBlockLds>(io, log_e, tile, pos_of, tid); else vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
+            return;
+        }
+    }
     if (!vio) {
 #pragma unroll
         for (uint32_t j = tid; j < T; j += kBlockLds) {
@@ -762,7 +781,6 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
     }
     __syncthreads();
     col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1, DECOMPOSE ? tc : nullptr);
-    if constexpr (kFast) { if (vio) { vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid); return; } }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
@@ -782,7 +800,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
                                                                const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
                                                                const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
                                                                uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c,
-                                                               const typename F::telem* __restrict__ c0t) {
+                                                               const typename F::telem* __restrict__ c0t, uint32_t log_v) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -792,24 +810,26 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
     const uint32_t log_hs = log_e - kb - 1;
     const size_t hs = (size_t)1 << log_hs;
     const uint32_t chunks_log = log_hs - log_c;
-    const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+    const size_t blk = ((size_t)blockIdx.x >> chunks_log) << log_v, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
     const size_t B = (blk << (log_hs + R)) + (chunk << log_c);
     const size_t c0 = (chunk << log_c);
-    auto pos_of = [=](uint32_t j) { return B + ((size_t)(j >> log_c) << log_hs) + (j & (C - 1)); };
+    const uint32_t log_T = log_c + R;
+    auto pos_of = [=](uint32_t j) { const uint32_t jj = j & (T - 1); return B + ((size_t)(j >> log_T) << (log_hs + R)) + ((size_t)(jj >> log_c) << log_hs) + (jj & (C - 1)); };
     bool vio = false;
     if constexpr (sizeof(E) == 4 && ECFFT_COL_PAD == 0) {
         IoDesc<F> chk = io; chk.src_stride = 1; chk.src_off = 0;           // this kernel reads src plainly and stores plainly
         const int m = io.st_mode;
         vio = T == kBlockLds * 16 && log_c >= 2 && (m == ST_PLAIN || m == ST_SCALE || m == ST_AXPBY) && vio_ok<F>(chk, log_e);
+        if (log_v && !vio) return;                                   // host only pairs spans on the vector path (never taken)
         if (vio) {
             IoDesc<F> pl = io; pl.src_stride = 1; pl.src_off = 0; pl.ld_mode = LD_PLAIN; pl.st_mode = ST_PLAIN;
-            vio_load<F, 4, kBlockLds>(pl, emask, tile, pos_of, tid);
+            if (log_v) vio_load<F, 8, kBlockLds>(pl, emask, tile, pos_of, tid); else vio_load<F, 4, kBlockLds>(pl, emask, tile, pos_of, tid);
             __syncthreads();
-            col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid);
-            vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
+            col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 1u << log_v);
+            if (log_v) vio_mid<F, 8, kBlockLds>(io, log_e, tile, pos_of, tid); else vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
             __syncthreads();
-            col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1, c0t);
-            vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid);
+            col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
+            if (log_v) vio_store<F, 8, kBlockLds>(pl, log_e, tile, pos_of, tid); else vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid);
             return;
         }
     }
