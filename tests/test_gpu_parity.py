@@ -120,6 +120,28 @@ def test_batched_enter_exit(gpu, gpu_tree, oracle_tree, field, n, count):
     assert np.array_equal(t.exit(ev, count=count), x)
 
 
+def test_batched_many_small_polynomials_use_the_throughput_kernels(gpu, gpu_tree, oracle_tree):
+    """64 polynomials of 4096 coefficients in one call: 2^18 elements per launch, so the full-size tiles and 512-thread low-level
+    kernels run on SHORT vectors (single small transforms take the latency variants since round 2); spot-checked
+    against the oracle polynomial by polynomial, round trip on all of them"""
+    F, ot = oracle_tree("secp256k1", 1 << 13)
+    t = gpu_tree("secp256k1", 1 << 13)
+    n, count = 4096, 64
+    x = rand_elems(F, n * count, 4242)
+    ev = t.enter(x, count=count)
+    for v in (0, 1, 31, 63):
+        assert np.array_equal(ev[v * n:(v + 1) * n], ot.enter(x[v * n:(v + 1) * n]))
+    assert np.array_equal(t.exit(ev, count=count), x)
+    r = rand_elems(F, n * count, 4343)
+    ex = t.exit(r, count=count)
+    for v in (0, 17, 63):
+        assert np.array_equal(ex[v * n:(v + 1) * n], ot.exit(r[v * n:(v + 1) * n]))
+    h = r[: (n // 2) * count]
+    got = t.extend(h, gpu.Moiety.S1, count=count)
+    for v in (0, 63):
+        assert np.array_equal(got[v * (n // 2):(v + 1) * (n // 2)], ot.extend(h[v * (n // 2):(v + 1) * (n // 2)], 1))
+
+
 @pytest.mark.parametrize("field", FIELDS)
 def test_fftree_new_from_leaves(gpu, oracle_tree, oracle_mod, field):
     """FFTree::new(leaves, rational_maps) (src/fftree.rs:42-70) from an externally built point set"""
