@@ -155,10 +155,6 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------
-    // EXTEND core: all 2*log(e) normalised stages, in place, on `total` elements = count vectors
-    // of length e = m/2 laid end to end.  src = parity of the moiety the data lives on.
-    // ------------------------------------------------------------------------------------------
-    // ------------------------------------------------------------------------------------------
     // EXTEND core: all 2*log(e) normalised stages on `total` elements = count vectors of length
     // e = m/2 laid end to end, as a chain of fused passes:
     //     [column passes: top decompose stages, <= 4 per pass] -> row pass (every stage with
@@ -235,7 +231,7 @@ public:
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
-                const unsigned lv = pair_spans(total, le, P.ka, log_ct);
+                const unsigned lv = pair_spans(total, le, P.ka, log_ct, d);
                 ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> (log_ct + lv))), dim3(kBlockLds), (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv, s,
                              d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c, T.c0t[tgt], (uint32_t)lv);
                 return true;
@@ -285,7 +281,7 @@ public:
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra;
                 const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
-                const unsigned lv = ct ? pair_spans(total, le, P.ka, log_ct) : 0;
+                const unsigned lv = ct ? pair_spans(total, le, P.ka, log_ct, d) : 0;
                 dim3 grid((unsigned)(total >> (log_ct + lv))); size_t lds = (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv;
                 if (P.kind == 0) {
                     if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
@@ -300,8 +296,13 @@ public:
     }
     // 4-byte fields, full-size column tiles: two consecutive spans (2h_ka-blocks; they read the same table entries) per workgroup
     // when the number of spans is even and the halved grid still fills the chip twice over
-    static unsigned pair_spans(size_t total, unsigned le, unsigned ka, unsigned log_ct) {
+    static unsigned pair_spans(size_t total, unsigned le, unsigned ka, unsigned log_ct, const IoDesc<F>& d) {
         if (sizeof(E) != 4 || ECFFT_COL_PAD != 0 || log_ct != kLogColTileMax) return 0;
+        // the paired form exists only on the kernels' 16-byte vector path: every buffer the pass touches must be 16-byte aligned
+        // (user buffers may be only element-aligned) and the operator must be one the vector path implements
+        auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        if (!al(d.src) || !al(d.dst) || !al(d.aux) || !al(d.aux_out) || d.ld_tr_logp || d.st_tr_logp || le < 2) return 0;
+        if (!((d.src_stride == 1 && d.src_off == 0) || (d.src_stride == 2 && d.src_off < 2))) return 0;
         const size_t nspans = total >> (le - ka);
         return (nspans >= 2 && (nspans & 1) == 0 && (total >> (log_ct + 1)) >= 512) ? 1u : 0u;
     }

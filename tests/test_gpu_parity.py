@@ -302,6 +302,29 @@ def test_config4_extend_2e22(gpu, gpu_tree, oracle_mod):
     assert np.array_equal(t.extend(s1, gpu.Moiety.S0), s0)
 
 
+def test_unaligned_device_buffers_take_the_scalar_paths(gpu, gpu_tree):
+    """M31 device buffers that are only element-aligned (4 bytes): the 16-byte vector IO and the paired-span column passes must
+    not be used for them.  Sizes on both sides of the pairing threshold; results must equal those of aligned buffers."""
+    import torch
+    for log_n in (13, 16, 23):
+        n = 1 << log_n
+        t = gpu_tree("m31", n)
+        rng = np.random.default_rng(log_n)
+        base = torch.from_numpy(rng.integers(0, 2**31 - 1, n + 8, dtype=np.uint32).view(np.int32)).cuda()
+        x_al = base[:n].clone()
+        x_un = base[1:n + 1]                               # data pointer offset by one element
+        assert x_un.data_ptr() % 16 != 0 and x_un.is_contiguous()
+        want = t.enter(base[1:n + 1].clone())
+        out_un = torch.empty(n + 8, dtype=torch.int32, device="cuda")[3:n + 3]          # unaligned output too
+        gpu.fftree._check(gpu.lib().ecfft_enter(t._h, x_un.data_ptr(), out_un.data_ptr(), n, 1, torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(out_un, want)
+        gpu.fftree._check(gpu.lib().ecfft_exit(t._h, out_un.data_ptr(), out_un.data_ptr(), n, 1, torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(out_un, base[1:n + 1])
+        h = base[1:n // 2 + 1]
+        assert torch.equal(t.extend(h, gpu.Moiety.S1), t.extend(h.clone(), gpu.Moiety.S1))
+        del x_al
+
+
 def test_one_context_from_two_threads_and_streams(gpu, gpu_tree, oracle_tree):
     """a context serialises its transforms: two host threads driving the SAME context on different torch streams must
     not corrupt each other's scratch (host mutex for the enqueues + HIP event across streams, ecfft_hip.h 'Threading')"""
