@@ -780,6 +780,20 @@ int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per
     return ECFFT_ERR_BAD_ARG;
 }
 
+int ecfft_device_alloc(int device, size_t bytes, void** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    return hipMalloc(out, bytes ? bytes : 1) == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+int ecfft_device_free(void* ptr) { return !ptr || hipFree(ptr) == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP; }
+int ecfft_device_sync(int device) {
+    DeviceGuard dev(device);
+    return dev.ok && hipDeviceSynchronize() == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+
 int ecfft_shader_clock(int field, int device, double* mhz) {
     if (field == ECFFT_FIELD_SECP256K1) return run_shader_clock<Secp256k1>(device, mhz);
     if (field == ECFFT_FIELD_M31) return run_shader_clock<M31>(device, mhz);

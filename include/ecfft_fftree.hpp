@@ -32,6 +32,29 @@ inline void check(int rc) {
 inline unsigned log2_floor(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
 inline void require(bool cond, const char* what) { if (!cond) throw std::invalid_argument(what); }
 
+// `ecfft_comm`: inter-GPU transport of the sharded transforms, one process per GPU (RCCL underneath, ecfft_hip.h).
+class Comm {
+public:
+    using UniqueId = std::array<unsigned char, ECFFT_COMM_ID_BYTES>;
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    Comm(Comm&& o) noexcept : c_(o.c_) { o.c_ = nullptr; }
+    ~Comm() { if (c_) ecfft_comm_destroy(c_); }
+    // rank 0 creates the id and hands it to the other ranks by any means (MPI, a file, a socket)
+    static UniqueId unique_id() { UniqueId id{}; check(ecfft_comm_get_unique_id(id.data())); return id; }
+    static Comm init_rank(const UniqueId& id, int world, int rank, int device) {
+        ecfft_comm* c = nullptr;
+        check(ecfft_comm_init_rank(id.data(), world, rank, device, &c));
+        return Comm(c);
+    }
+    int rank() const { return ecfft_comm_rank(c_); }
+    int world() const { return ecfft_comm_world(c_); }
+    ecfft_comm* raw() const { return c_; }
+private:
+    explicit Comm(ecfft_comm* c) : c_(c) {}
+    ecfft_comm* c_;
+};
+
 template <class F>
 class FFTree {
 public:
@@ -103,6 +126,11 @@ public:
     void enter_device(const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter(ctx_, coeffs, evals, n, ECFFT_MEM_DEVICE, stream)); }
     void exit_device(const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit(ctx_, evals, coeffs, n, ECFFT_MEM_DEVICE, stream)); }
     void extend_device(const Elem* in, Elem* out, size_t e, Moiety m, size_t count, void* stream) const { check(ecfft_extend(ctx_, in, out, e, (int)m, count, ECFFT_MEM_DEVICE, stream)); }
+
+    // ONE transform split over the ranks of `comm` (device pointers: this rank's block shard of len / world elements)
+    void extend_sharded(const Comm& comm, const Elem* in, Elem* out, size_t e, Moiety m, void* stream) const { check(ecfft_extend_sharded(ctx_, comm.raw(), in, out, e, (int)m, stream)); }
+    void enter_sharded(const Comm& comm, const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter_sharded(ctx_, comm.raw(), coeffs, evals, n, stream)); }
+    void exit_sharded(const Comm& comm, const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit_sharded(ctx_, comm.raw(), evals, coeffs, n, stream)); }
 
     // pub tables of the subtree with m leaves (src/fftree.rs:24-38, 489-496)
     std::vector<Elem> table(int which, size_t m) const {

@@ -191,6 +191,12 @@ int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per
  * to turn rocprofv3 instruction counts into issue-cycle fractions. */
 int ecfft_shader_clock(int field, int device, double* mhz);
 
+/* Device-buffer helpers for hosts without HIP bindings (examples/sharded_extend.cpp is plain C++ over this ABI): allocate / free
+ * HBM on `device`, wait for the device. */
+int ecfft_device_alloc(int device, size_t bytes, void** out);
+int ecfft_device_free(void* ptr);
+int ecfft_device_sync(int device);
+
 /* synchronous copy on the CURRENT device: kind 0 device -> host, 1 host -> device, 2 device -> device.  Lets a host language
  * without HIP bindings implement the exchange callback above — ecfft_amd/distributed.py does, over gloo. */
 int ecfft_device_copy(void* dst, const void* src, size_t bytes, int kind);

@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXAMPLES = ["interp_eval", "bench_fftree"]
+EXAMPLES = ["interp_eval", "bench_fftree", "sharded_extend"]
 
 
 def _build(name, outdir):
