@@ -150,6 +150,14 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
 struct Quad { uint32_t v[4]; };
 __device__ __forceinline__ Quad ldq(const uint32_t* p) { uint4 t = *reinterpret_cast<const uint4*>(p); return Quad{{t.x, t.y, t.z, t.w}}; }
 __device__ __forceinline__ void stq(uint32_t* p, const Quad& q) { *reinterpret_cast<uint4*>(p) = make_uint4(q.v[0], q.v[1], q.v[2], q.v[3]); }
+// four consecutive 4-byte table entries starting at entry idx (16-byte aligned), uniform base pointer in the GLOBAL address space + 32-bit byte offset (see ldt below)
+__device__ __forceinline__ Quad ldq_tab(const uint32_t* __restrict__ base, uint32_t idx) {
+    typedef const __attribute__((address_space(1))) char* gchar;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* gq;
+    const u32x4 t = *(gq)((gchar)(reinterpret_cast<const char*>(base)) + (size_t)(idx * 4u));
+    return Quad{{t.x, t.y, t.z, t.w}};
+}
 // four elements at p[stride*k + off], k = 0..3, stride 1 (off 0) or 2 (off 0 / 1)
 __device__ __forceinline__ Quad ldq_strided(const uint32_t* p, uint32_t stride, uint32_t off) {
     if (stride == 1) return ldq(p);
@@ -169,13 +177,14 @@ __device__ __forceinline__ bool vio_ok(const IoDesc<F>& io, uint32_t log_e) {
     return ok;
 }
 template <class F, int NQ, int BLK, class PosFn>
-__device__ __forceinline__ void vio_load(const IoDesc<F>& io, size_t emask, typename F::elem* tile, PosFn pos_of, uint32_t tid) {
+__device__ __forceinline__ void vio_load(const IoDesc<F>& io, size_t emask, typename F::elem* tile, PosFn pos_of, uint32_t tid0) {
+    const uint32_t tid = tid0;   // callers that split a tile into batches pass tid + batch*NQ*BLK (quad c of the batch = index 4*(tid + c*BLK))
     Quad d[NQ], t[NQ];
 #pragma unroll
     for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); d[c] = ldq_strided(io.src + (size_t)io.src_stride * pos, io.src_stride, io.src_off); }
     if (io.ld_mode == LD_SCALE) {
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); t[c] = ldq(io.ld_tbl + (pos & emask)); }
+        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); t[c] = ldq_tab(io.ld_tbl, (uint32_t)(pos & emask)); }
 #pragma unroll
         for (int c = 0; c < NQ; ++c)
 #pragma unroll
@@ -193,13 +202,13 @@ __device__ __forceinline__ void vio_store(const IoDesc<F>& io, uint32_t log_e, c
     const int m = io.st_mode;
     if (m != ST_PLAIN) {
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); a[c] = ldq(io.st_a + (pos & emask)); }
+        for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); a[c] = ldq_tab(io.st_a, (uint32_t)(pos & emask)); }
     }
     if (m == ST_AXPBY || m == ST_EXIT_SPLIT) {
 #pragma unroll
         for (int c = 0; c < NQ; ++c) {
             const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK));
-            b[c] = ldq(io.st_b + (pos & emask));
+            b[c] = ldq_tab(io.st_b, (uint32_t)(pos & emask));
             y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off);
         }
     }
@@ -235,9 +244,9 @@ __device__ __forceinline__ void vio_mid(const IoDesc<F>& io, uint32_t log_e, typ
     for (int c = 0; c < NQ; ++c) {
         const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)), i = pos & emask;
         x[c] = ldq(tile + 4u * (tid + (uint32_t)c * BLK));
-        if (m != ST_PLAIN) a[c] = ldq(io.st_a + i);
-        if (m == ST_AXPBY) { b[c] = ldq(io.st_b + i); y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off); }
-        if (io.ld_mode == LD_SCALE) l[c] = ldq(io.ld_tbl + i);
+        if (m != ST_PLAIN) a[c] = ldq_tab(io.st_a, (uint32_t)i);
+        if (m == ST_AXPBY) { b[c] = ldq_tab(io.st_b, (uint32_t)i); y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off); }
+        if (io.ld_mode == LD_SCALE) l[c] = ldq_tab(io.ld_tbl, (uint32_t)i);
     }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
@@ -270,7 +279,7 @@ __device__ __forceinline__ void vio_enter_store(const typename F::elem* tile, co
     for (int c = 0; c < NQ; ++c) {
         uint32_t ju, jv; size_t i, bb; idx(c, ju, jv, i, bb);
         u0[c] = ldq(src + bb + i); v0[c] = ldq(src + bb + e + i);
-        tx[c] = ldq(xe + i); tw[c] = ldq(w1 + i); twx[c] = ldq(w1x + i);
+        tx[c] = ldq_tab(xe, (uint32_t)i); tw[c] = ldq_tab(w1, (uint32_t)i); twx[c] = ldq_tab(w1x, (uint32_t)i);
         U[c] = ldq(tile + ju); V[c] = ldq(tile + jv);
     }
 #pragma unroll
@@ -378,6 +387,17 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
 // consecutive elements in one visit with wave-uniform (scalar) table constants.  25 sweeps of an 8192-element tile become
 // 7 visits.
 // ---------------------------------------------------------------------------------------------
+// table entry `idx` of a table whose base pointer is wave-uniform: 32-bit BYTE offset, so the load is "SGPR base + 32-bit lane
+// offset" (global_load ... v_off, s[base:base+1]) instead of a 64-bit per-lane address built with v_lshl_add_u64
+// The pointer is also cast to the GLOBAL address space: table pointers that were themselves loaded from memory (LevelTables) are
+// generic, and generic (flat_load) accesses count against the LDS counter as well as the vector-memory one.
+template <class TE>
+__device__ __forceinline__ TE ldt(const TE* __restrict__ base, uint32_t idx) {
+    typedef const __attribute__((address_space(1))) char* gchar;
+    typedef const __attribute__((address_space(1))) TE* gte;
+    return *(gte)((gchar)(reinterpret_cast<const char*>(base)) + (size_t)(idx * (uint32_t)sizeof(TE)));
+}
+
 template <class F, bool DEC>
 __device__ __forceinline__ void bfly(typename F::elem& a, typename F::elem& b, const typename F::telem& t0, const typename F::telem& t1) {
     using E = typename F::elem;
@@ -406,7 +426,7 @@ __device__ __forceinline__ void radix_step(typename F::elem* a, const typename F
         for (int sp = 0; sp < NS; ++sp) {
             const uint32_t off = e - 2 * (tstride << sp) + tbase[g];
 #pragma unroll
-            for (int m = 0; m < (1 << sp); ++m) { t0[g][(1 << sp) - 1 + m] = ta[off + (uint32_t)m * tstride]; t1[g][(1 << sp) - 1 + m] = tb[off + (uint32_t)m * tstride]; }
+            for (int m = 0; m < (1 << sp); ++m) { t0[g][(1 << sp) - 1 + m] = ldt(ta, off + (uint32_t)m * tstride); t1[g][(1 << sp) - 1 + m] = ldt(tb, off + (uint32_t)m * tstride); }
         }
     }
     __syncthreads();
@@ -483,11 +503,11 @@ __device__ __forceinline__ void tail_stages(typename F::elem* a, const typename 
             const uint32_t off = e - 2 * (1u << lh);
 #pragma unroll
             for (int j = 0; j < EPT; ++j)
-                if (!(j & (1 << lh))) bfly<F, true>(x[j], x[j + (1 << lh)], np0[off + (j & ((1 << lh) - 1))], dinv[off + (j & ((1 << lh) - 1))]);
+                if (!(j & (1 << lh))) bfly<F, true>(x[j], x[j + (1 << lh)], ldt(np0, off + (j & ((1 << lh) - 1))), ldt(dinv, off + (j & ((1 << lh) - 1))));
         }
     }
     {
-        const typename F::telem c0 = inner[0], c1 = inner[1];
+        const typename F::telem c0 = ldt(inner, 0), c1 = ldt(inner, 1);
 #pragma unroll
         for (int j = 0; j < EPT; j += 2) { E d = F::sub(x[j + 1], x[j]); E o0 = F::tmul_add(c0, d, x[j]); x[j + 1] = F::tmul_add(c1, d, x[j]); x[j] = o0; }
     }
@@ -497,7 +517,7 @@ __device__ __forceinline__ void tail_stages(typename F::elem* a, const typename 
             const uint32_t off = e - 2 * (1u << lh);
 #pragma unroll
             for (int j = 0; j < EPT; ++j)
-                if (!(j & (1 << lh))) bfly<F, false>(x[j], x[j + (1 << lh)], p0[off + (j & ((1 << lh) - 1))], p1[off + (j & ((1 << lh) - 1))]);
+                if (!(j & (1 << lh))) bfly<F, false>(x[j], x[j + (1 << lh)], ldt(p0, off + (j & ((1 << lh) - 1))), ldt(p1, off + (j & ((1 << lh) - 1))));
         }
     }
 #pragma unroll
@@ -765,10 +785,13 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
     if constexpr (kFast) {
         if (log_v && !vio) return;                                   // host only pairs spans on the vector path (never taken)
         if (vio) {
-            if (log_v) vio_load<F, 8, kBlockLds>(io, emask, tile, pos_of, tid); else vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid);
+            // paired spans: two batches of four quads per thread (one batch of eight needs > 128 VGPRs and spills)
+#pragma unroll 1
+            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid + b * 4u * kBlockLds);
             __syncthreads();
             col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
-            if (log_v) vio_store<F, 8, kBlockLds>(io, log_e, tile, pos_of, tid); else vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
+#pragma unroll 1
+            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid + b * 4u * kBlockLds);
             return;
         }
     }
@@ -823,13 +846,16 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
         if (log_v && !vio) return;                                   // host only pairs spans on the vector path (never taken)
         if (vio) {
             IoDesc<F> pl = io; pl.src_stride = 1; pl.src_off = 0; pl.ld_mode = LD_PLAIN; pl.st_mode = ST_PLAIN;
-            if (log_v) vio_load<F, 8, kBlockLds>(pl, emask, tile, pos_of, tid); else vio_load<F, 4, kBlockLds>(pl, emask, tile, pos_of, tid);
+#pragma unroll 1
+            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_load<F, 4, kBlockLds>(pl, emask, tile, pos_of, tid + b * 4u * kBlockLds);
             __syncthreads();
             col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 1u << log_v);
-            if (log_v) vio_mid<F, 8, kBlockLds>(io, log_e, tile, pos_of, tid); else vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid);
+#pragma unroll 1
+            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid + b * 4u * kBlockLds);
             __syncthreads();
             col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
-            if (log_v) vio_store<F, 8, kBlockLds>(pl, log_e, tile, pos_of, tid); else vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid);
+#pragma unroll 1
+            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_store<F, 4, kBlockLds>(pl, log_e, tile, pos_of, tid + b * 4u * kBlockLds);
             return;
         }
     }
@@ -1059,7 +1085,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
                     Quad x[NQ], t[NQ];
                     const typename F::telem* wi = L.winv[0];
 #pragma unroll
-                    for (int c = 0; c < NQ; ++c) { const uint32_t j = 4u * (tid + (uint32_t)c * BLK); t[c] = ldq(wi + (j & (e - 1))); x[c] = ldq(cur + j); }
+                    for (int c = 0; c < NQ; ++c) { const uint32_t j = 4u * (tid + (uint32_t)c * BLK); t[c] = ldq_tab(wi, j & (e - 1)); x[c] = ldq(cur + j); }
 #pragma unroll
                     for (int c = 0; c < NQ; ++c) {
 #pragma unroll
@@ -1076,7 +1102,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
 #pragma unroll
                     for (int c = 0; c < NP; ++c) {
                         const uint32_t g = 4u * (tid + (uint32_t)c * BLK), i = g & (e - 1), bb = (g >> le) << l;
-                        tx[c] = ldq(xe + i); tw[c] = ldq(w1 + i); twx[c] = ldq(w1x + i);
+                        tx[c] = ldq_tab(xe, (uint32_t)i); tw[c] = ldq_tab(w1, (uint32_t)i); twx[c] = ldq_tab(w1x, (uint32_t)i);
                         u0[c] = ldq(cur + bb + i); v0[c] = ldq(cur + bb + e + i); U1[c] = ldq(work + bb + i); V1[c] = ldq(work + bb + e + i);
                     }
 #pragma unroll
@@ -1186,7 +1212,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
                 // the level's five pointwise steps on quads of the pair index g (loads first), the four EXTEND cores between them
                 constexpr int NP = (int)(nh / (4 * BLK));
                 auto gq = [=](int c) { return 4u * (tid + (uint32_t)c * BLK); };
-                auto tq = [=](const typename F::telem* t, int c) { return ldq(t + (gq(c) & (e - 1))); };
+                auto tq = [=](const typename F::telem* t, int c) { return ldq_tab(t, gq(c) & (e - 1)); };
                 auto evenq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.x, a.z, b.x, b.z}}; };
                 auto oddq = [=](int c) { uint4 a = *reinterpret_cast<const uint4*>(cur + 2 * gq(c)), b = *reinterpret_cast<const uint4*>(cur + 2 * gq(c) + 4); return Quad{{a.y, a.w, b.y, b.w}}; };
                 {
