@@ -139,6 +139,29 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
     return r;
 }
 
+// table entry `idx` of a table whose base pointer is wave-uniform: 32-bit BYTE offset, so the load is "SGPR base + 32-bit lane
+// offset" (global_load ... v_off, s[base:base+1]) instead of a 64-bit per-lane address built with v_lshl_add_u64
+// The pointer is also cast to the GLOBAL address space: table pointers that were themselves loaded from memory (LevelTables) are
+// generic, and generic (flat_load) accesses count against the LDS counter as well as the vector-memory one.
+template <class TE>
+__device__ __forceinline__ TE ldt(const TE* __restrict__ base, uint32_t idx) {
+    typedef const __attribute__((address_space(1))) char* gchar;
+    if constexpr (sizeof(TE) == 4) {
+        typedef const __attribute__((address_space(1))) TE* gte;
+        return *(gte)((gchar)(reinterpret_cast<const char*>(base)) + (size_t)(idx * (uint32_t)sizeof(TE)));
+    } else {
+        // multi-word constants (secp256k1: 64 bytes): 16-byte global loads; 64-bit offset (tables may exceed 4 GiB)
+        static_assert(sizeof(TE) % 16 == 0, "table constants are whole 16-byte words");
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) u32x4* gq;
+        const gq p = (gq)((gchar)(reinterpret_cast<const char*>(base)) + (size_t)idx * sizeof(TE));
+        TE r;
+        u32x4* rp = reinterpret_cast<u32x4*>(&r);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(TE) / 16); ++k) rp[k] = p[k];
+        return r;
+    }
+}
 // ---------------------------------------------------------------------------------------------
 // Tile load / store for 4-byte fields, four consecutive elements ("quad") at a time.  The element-at-a-time loops of the
 // generic kernels compile to a loop that waits for every 4-byte load before issuing the next one — 16 serial HBM round
@@ -338,7 +361,7 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
             const bool act = tid < 2 * npairs, hi = tid >= npairs;
             const uint32_t g = hi ? tid - npairs : tid, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
             E x, y; typename F::telem t;
-            if (act) { x = a_[idx]; y = a_[idx + h]; t = DEC ? (hi ? tb[i] : tc[i]) : (hi ? tb[i] : ta[i]); }
+            if (act) { x = a_[idx]; y = a_[idx + h]; t = DEC ? (hi ? ldt(tb, i) : ldt(tc, i)) : (hi ? ldt(tb, i) : ldt(ta, i)); }
             __syncthreads();
             if (act) {
                 if (DEC) { const E d = F::sub(y, x); if (hi) a_[idx + h] = F::tmul(t, d); else a_[idx] = F::tmul_add(t, d, x); }
@@ -369,8 +392,8 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
     for (uint32_t g = tid; g < npairs; g += BLK) {
         const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
         E a = a_[idx], b = a_[idx + h];
-        if (DEC) { E q1 = F::tmul(tb[i], F::sub(b, a)); a_[idx] = F::tmul_add(ta[i], q1, a); a_[idx + h] = q1; }
-        else { a_[idx] = F::tmul_add(ta[i], b, a); a_[idx + h] = F::tmul_add(tb[i], b, a); }
+        if (DEC) { E q1 = F::tmul(ldt(tb, i), F::sub(b, a)); a_[idx] = F::tmul_add(ldt(ta, i), q1, a); a_[idx + h] = q1; }
+        else { a_[idx] = F::tmul_add(ldt(ta, i), b, a); a_[idx + h] = F::tmul_add(ldt(tb, i), b, a); }
     }
 }
 
@@ -387,17 +410,6 @@ __device__ __forceinline__ void stage_sweep(typename F::elem* a_, const typename
 // consecutive elements in one visit with wave-uniform (scalar) table constants.  25 sweeps of an 8192-element tile become
 // 7 visits.
 // ---------------------------------------------------------------------------------------------
-// table entry `idx` of a table whose base pointer is wave-uniform: 32-bit BYTE offset, so the load is "SGPR base + 32-bit lane
-// offset" (global_load ... v_off, s[base:base+1]) instead of a 64-bit per-lane address built with v_lshl_add_u64
-// The pointer is also cast to the GLOBAL address space: table pointers that were themselves loaded from memory (LevelTables) are
-// generic, and generic (flat_load) accesses count against the LDS counter as well as the vector-memory one.
-template <class TE>
-__device__ __forceinline__ TE ldt(const TE* __restrict__ base, uint32_t idx) {
-    typedef const __attribute__((address_space(1))) char* gchar;
-    typedef const __attribute__((address_space(1))) TE* gte;
-    return *(gte)((gchar)(reinterpret_cast<const char*>(base)) + (size_t)(idx * (uint32_t)sizeof(TE)));
-}
-
 template <class F, bool DEC>
 __device__ __forceinline__ void bfly(typename F::elem& a, typename F::elem& b, const typename F::telem& t0, const typename F::telem& t1) {
     using E = typename F::elem;
@@ -990,7 +1002,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
             for (uint32_t k = 0; k < k_inner; ++k) {
                 const uint32_t lh = log_e - k - 1, h = 1u << lh, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
                 const size_t off = e - 2 * (size_t)h + i;
-                const typename F::telem t = hi ? T.dinv[srcpar][off] : T.c0t[srcpar][off];
+                const typename F::telem t = hi ? ldt(T.dinv[srcpar], (uint32_t)off) : ldt(T.c0t[srcpar], (uint32_t)off);
                 const E x = a[idx], y = a[idx + h];
                 __syncthreads();
                 const E d = F::sub(y, x);
@@ -998,7 +1010,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
                 __syncthreads();
             }
             if (log_e > 0) {
-                const typename F::telem t = T.inner[srcpar][hi ? 1 : 0];
+                const typename F::telem t = ldt(T.inner[srcpar], hi ? 1u : 0u);
                 const E x = a[2 * g], y = a[2 * g + 1];
                 __syncthreads();
                 a[2 * g + (hi ? 1 : 0)] = F::tmul_add(t, F::sub(y, x), x);
@@ -1007,7 +1019,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
             for (uint32_t k = k_inner; k-- > 0;) {
                 const uint32_t lh = log_e - k - 1, h = 1u << lh, i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
                 const size_t off = e - 2 * (size_t)h + i;
-                const typename F::telem t = hi ? T.p1[tgt][off] : T.p0[tgt][off];
+                const typename F::telem t = hi ? ldt(T.p1[tgt], (uint32_t)off) : ldt(T.p0[tgt], (uint32_t)off);
                 const E x = a[idx], y = a[idx + h];
                 __syncthreads();
                 a[idx + (hi ? h : 0)] = F::tmul_add(t, y, x);
@@ -1028,7 +1040,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
         __syncthreads();
     }
     if (log_e > 0) {                                    // merged innermost stage pair (h = 1)
-        const typename F::telem c0 = T.inner[srcpar][0], c1 = T.inner[srcpar][1];
+        const typename F::telem c0 = ldt(T.inner[srcpar], 0u), c1 = ldt(T.inner[srcpar], 1u);
         for (uint32_t g = tid; g < npairs; g += BLK) {
             E x = a[2 * g], y = a[2 * g + 1];
             E d = F::sub(y, x);
@@ -1124,7 +1136,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
                 continue;
             }
         }
-        for (uint32_t j = tid; j < T; j += BLK) work[j] = F::tmul(L.winv[0][j & (e - 1)], cur[j]);
+        for (uint32_t j = tid; j < T; j += BLK) work[j] = F::tmul(ldt(L.winv[0], j & (e - 1)), cur[j]);
         __syncthreads();
         lds_extend_core<F, BLK>(work, T, le, L, 0);
         // combine (:155-159): block [u0|v0] + extended [U1|V1] -> interleaved evaluations; results are held in
@@ -1133,8 +1145,8 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
             const bool hi = tid >= npairs;
             const uint32_t g = hi ? tid - npairs : tid, i = g & (e - 1), bb = (g >> le) << l;
             E r;
-            if (!hi) r = F::tmul_add(L.xe[i], cur[bb + e + i], cur[bb + i]);
-            else r = F::tmul_add(L.w1x[i], work[bb + e + i], F::tmul(L.w[1][i], work[bb + i]));
+            if (!hi) r = F::tmul_add(ldt(L.xe, i), cur[bb + e + i], cur[bb + i]);
+            else r = F::tmul_add(ldt(L.w1x, i), work[bb + e + i], F::tmul(ldt(L.w[1], i), work[bb + i]));
             __syncthreads();
             cur[bb + 2 * i + (hi ? 1 : 0)] = r;
             __syncthreads();
@@ -1145,8 +1157,8 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1), bb = (g >> le) << l;
             E u0 = cur[bb + i], v0 = cur[bb + e + i], U1 = work[bb + i], V1 = work[bb + e + i];
-            ev[c] = F::tmul_add(L.xe[i], v0, u0);
-            od[c] = F::tmul_add(L.w1x[i], V1, F::tmul(L.w[1][i], U1));
+            ev[c] = F::tmul_add(ldt(L.xe, i), v0, u0);
+            od[c] = F::tmul_add(ldt(L.w1x, i), V1, F::tmul(ldt(L.w[1], i), U1));
         }
         __syncthreads();
 #pragma unroll
@@ -1287,22 +1299,22 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
                 continue;
             }
         }
-        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(L.A1[g & (e - 1)], cur[2 * g]);
+        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(ldt(L.A1, g & (e - 1)), cur[2 * g]);
         __syncthreads();
         lds_extend_core<F, BLK>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
-            E r = F::tmul_add(L.NB2[i], G[g], F::tmul(L.B1[i], cur[2 * g + 1]));
+            E r = F::tmul_add(ldt(L.NB2, i), G[g], F::tmul(ldt(L.B1, i), cur[2 * g + 1]));
             G[g] = r; H[g] = r;
         }
         __syncthreads();
         lds_extend_core<F, BLK>(G, nh, le, L, 1);
-        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(L.C1[g & (e - 1)], G[g]);
+        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(ldt(L.C1, g & (e - 1)), G[g]);
         __syncthreads();
         lds_extend_core<F, BLK>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
-            G[g] = F::tmul_add(L.NB2[i], G[g], F::tmul(L.D1[i], H[g]));
+            G[g] = F::tmul_add(ldt(L.NB2, i), G[g], F::tmul(ldt(L.D1, i), H[g]));
         }
         __syncthreads();
         lds_extend_core<F, BLK>(G, nh, le, L, 1);
@@ -1310,8 +1322,8 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1);
-            u[c] = F::tmul(L.w[0][i], G[g]);
-            v[c] = F::tmul(L.xie[i], F::sub(cur[2 * g], u[c]));
+            u[c] = F::tmul(ldt(L.w[0], i), G[g]);
+            v[c] = F::tmul(ldt(L.xie, i), F::sub(cur[2 * g], u[c]));
         }
         __syncthreads();
 #pragma unroll
