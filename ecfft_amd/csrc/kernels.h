@@ -296,18 +296,19 @@ __device__ __forceinline__ void vio_mid(const IoDesc<F>& io, uint32_t log_e, typ
 template <class F, int NQ, class IdxFn>
 __device__ __forceinline__ void vio_enter_store(const typename F::elem* tile, const typename F::elem* __restrict__ src, typename F::elem* __restrict__ dst,
                                                 const typename F::telem* __restrict__ xe, const typename F::telem* __restrict__ w1,
-                                                const typename F::telem* __restrict__ w1x, size_t e, IdxFn idx) {
+                                                const typename F::telem* __restrict__ w1x, size_t e, IdxFn idx, int cbase = 0) {
+    // cbase: first quad of this batch (callers run several small batches: 7 live quads per pair-quad is 28 VGPRs)
     Quad u0[NQ], v0[NQ], tx[NQ], tw[NQ], twx[NQ], U[NQ], V[NQ];
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
-        uint32_t ju, jv; size_t i, bb; idx(c, ju, jv, i, bb);
+        uint32_t ju, jv; size_t i, bb; idx(cbase + c, ju, jv, i, bb);
         u0[c] = ldq(src + bb + i); v0[c] = ldq(src + bb + e + i);
         tx[c] = ldq_tab(xe, (uint32_t)i); tw[c] = ldq_tab(w1, (uint32_t)i); twx[c] = ldq_tab(w1x, (uint32_t)i);
         U[c] = ldq(tile + ju); V[c] = ldq(tile + jv);
     }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
-        uint32_t ju, jv; size_t i, bb; idx(c, ju, jv, i, bb);
+        uint32_t ju, jv; size_t i, bb; idx(cbase + c, ju, jv, i, bb);
         Quad lo, hi;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -572,7 +573,12 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     constexpr int kNQ = kFast ? (1 << (LOG_TILE_CT > 0 ? LOG_TILE_CT : 2)) / (4 * kBlockRow) : 1;
     bool vio = false;
     if constexpr (kFast) vio = vio_ok<F>(io, log_e);
-    if constexpr (kFast) { if (vio) vio_load<F, kNQ, kBlockRow>(io, emask, tile, [=](uint32_t j) { return base + j; }, tid); }
+    if constexpr (kFast) {
+        if (vio) {
+#pragma unroll 1
+            for (uint32_t b = 0; b < (uint32_t)kNQ / 4; ++b) vio_load<F, 4, kBlockRow>(io, emask, tile, [=](uint32_t j) { return base + j; }, tid + b * 4u * kBlockRow);
+        }
+    }
     if (!vio) {
 #pragma unroll
         for (uint32_t j = tid; j < T; j += kBlockRow) tile[j] = io_load<F>(io, base + j, emask);
@@ -624,10 +630,12 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         if constexpr (kFast) {
             auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
             if (log_e >= 2 && al(io.aux) && al(io.dst) && al(io.st_a) && al(io.st_b) && al(io.st_c)) {
-                vio_enter_store<F, kNQ / 2>(tile, io.aux, io.dst, io.st_a, io.st_c, io.st_b, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
-                    const uint32_t g = 4u * (tid + (uint32_t)c * kBlockRow), ii = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
-                    ju = lb + ii; jv = lb + (uint32_t)e + ii; i = ii; bb = base + lb;
-                });
+#pragma unroll 1
+                for (int cb = 0; cb < kNQ / 2; cb += 2)
+                    vio_enter_store<F, 2>(tile, io.aux, io.dst, io.st_a, io.st_c, io.st_b, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
+                        const uint32_t g = 4u * (tid + (uint32_t)c * kBlockRow), ii = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
+                        ju = lb + ii; jv = lb + (uint32_t)e + ii; i = ii; bb = base + lb;
+                    }, cb);
                 return;
             }
         }
@@ -642,7 +650,13 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         }
         return;
     }
-    if constexpr (kFast) { if (vio) { vio_store<F, kNQ, kBlockRow>(io, log_e, tile, [=](uint32_t j) { return base + j; }, tid); return; } }
+    if constexpr (kFast) {
+        if (vio) {
+#pragma unroll 1
+            for (uint32_t b = 0; b < (uint32_t)kNQ / 4; ++b) vio_store<F, 4, kBlockRow>(io, log_e, tile, [=](uint32_t j) { return base + j; }, tid + b * 4u * kBlockRow);
+            return;
+        }
+    }
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
 }
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
             __syncthreads();
             col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 1u << log_v);
 #pragma unroll 1
-            for (uint32_t b = 0; b < (1u << log_v); ++b) vio_mid<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid + b * 4u * kBlockLds);
+            for (uint32_t b = 0; b < (2u << log_v); ++b) vio_mid<F, 2, kBlockLds>(io, log_e, tile, pos_of, tid + b * 2u * kBlockLds);   // 2 quads at a time: 4 spill
             __syncthreads();
             col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
 #pragma unroll 1
@@ -933,10 +947,12 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_enter
             __syncthreads();
             col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 2);
             const size_t bb0 = b << (log_e + 1);
-            vio_enter_store<F, 4>(tile, src, dst, xe, w1, w1x, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
-                const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds), r = j >> log_c, cc = j & (C - 1);
-                ju = j; jv = j + (C << R); i = ((size_t)r << log_hs) + c0 + cc; bb = bb0;
-            });
+#pragma unroll 1
+            for (int cb = 0; cb < 4; cb += 2)
+                vio_enter_store<F, 2>(tile, src, dst, xe, w1, w1x, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
+                    const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds), r = j >> log_c, cc = j & (C - 1);
+                    ju = j; jv = j + (C << R); i = ((size_t)r << log_hs) + c0 + cc; bb = bb0;
+                }, cb);
             return;
         }
     }
