@@ -32,19 +32,22 @@ struct M31 {
     }
     __host__ __device__ static inline elem mul(elem t, elem x) { return red64((uint64_t)t * x); }
     __host__ __device__ static inline elem mul_add(elem t, elem x, elem c) { return red64((uint64_t)t * x + c); }
-    __host__ __device__ static inline telem to_table(elem t) { return t; }
+    // A table constant is stored DOUBLED, t2 = 2t (< 2^32 for canonical t).  Then the 64-bit product t2*x + 2c = 2(t*x + c) has
+    // floor((t*x + c) / 2^31) in its HIGH word and 2*((t*x + c) mod 2^31) in its LOW word: the 31-bit split of the pseudo-Mersenne
+    // fold is "low word >> 1" and "high word" — two plain two-operand VALU instructions instead of v_and + the 4-cycle v_alignbit.
+    __host__ __device__ static inline telem to_table(elem t) { return t << 1; }
     // Table x data inside the butterfly kernels works on the LAZY range [0, p] (p itself = a second representative of 0):
     // for t <= p-1 and x, c <= p the product t*x + c <= p^2 < 2^62, so lo + hi <= 2^32 - 2 and the second fold lands in
-    // [0, p] again — the final conditional subtract of the canonical reduction (2 of 9 instructions) is dropped.  sub()
-    // maps [0, p] x [0, p] into [0, p] as written.  Every value that leaves a kernel for HBM goes through canon().
-    __host__ __device__ static inline elem red64_lazy(uint64_t t) {
-        uint32_t lo = (uint32_t)t & P, hi = (uint32_t)(t >> 31);
-        uint32_t r = lo + hi;                     // <= 2^32 - 2
+    // [0, p] again — the final conditional subtract of the canonical reduction is dropped — 6 instead of 9 instructions per
+    // multiply.  sub() maps [0, p] x [0, p] into [0, p] as written.  Every value that leaves a kernel for HBM goes through canon().
+    __host__ __device__ static inline elem fold2_lazy(uint64_t twice) {      // twice = 2*(t*x + c) < 2^63
+        uint32_t r = ((uint32_t)twice >> 1) + (uint32_t)(twice >> 32);      // lo31 + hi <= 2^32 - 2
         uint32_t d = r - P;                       // second fold as subtract + unsigned min (2 plain VALU instructions instead of
         return d < r ? d : r;                     // and / shift / add): r >= p -> r - p in [0, p]; r < p -> the difference wraps, keep r
     }
-    __host__ __device__ static inline elem tmul(telem t, elem x) { return red64_lazy((uint64_t)t * x); }
-    __host__ __device__ static inline elem tmul_add(telem t, elem x, elem c) { return red64_lazy((uint64_t)t * x + c); }
+    __host__ __device__ static inline elem red64_lazy(uint64_t t) { return fold2_lazy(t << 1); }   // plain (undoubled) operand; t < 2^62 + 2^31
+    __host__ __device__ static inline elem tmul(telem t2, elem x) { return fold2_lazy((uint64_t)t2 * x); }
+    __host__ __device__ static inline elem tmul_add(telem t2, elem x, elem c) { return fold2_lazy((uint64_t)t2 * x + ((uint64_t)c << 1)); }
     __host__ __device__ static inline elem canon(elem x) { uint32_t d = x - P; return d < x ? d : x; }   // p -> 0
     __host__ __device__ static inline elem sqr(elem a) { return mul(a, a); }
     __host__ __device__ static inline elem pow_u64(elem a, uint64_t e) {
