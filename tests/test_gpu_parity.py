@@ -233,6 +233,10 @@ def test_full_size_properties(gpu, gpu_tree, oracle_mod, field, log_n):
     ea, eb = t.enter(a), t.enter(b)
     assert np.array_equal(t.exit(ea), a)
     assert np.array_equal(t.enter(F.add(a, b)), F.add(ea, eb))
+    # EXIT of ARBITRARY evaluations: ENTER is pinned as the evaluation map (Horner spot checks + linearity), so
+    # ENTER(EXIT(r)) == r proves EXIT(r) is the interpolant of r — a wrong-but-self-inverse pass cannot satisfy both directions
+    r = rand_elems(F, n, 3)
+    assert np.array_equal(t.enter(t.exit(r)), r)
     leaves = t.leaves()
     idx = np.array([0, 1, 2, n // 2 - 1, n // 2, n - 2, n - 1, 12345 % n, 777777 % n])
     assert np.array_equal(ea[idx], F.horner(a, leaves[idx]))
