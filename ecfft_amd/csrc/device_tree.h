@@ -593,7 +593,7 @@ public:
     // the default size use 4x smaller tiles: 256 elements, 128-thread low-level kernels, one wave per SIMD.
     static constexpr unsigned kLogLowSmall = 8, kBlockLowSmall = 128, kSmallTiles = 256;
     static bool small_launch(size_t total) { return sizeof(E) == 32 && (total >> kLogLow) < kSmallTiles && total >= ((size_t)1 << kLogLowSmall); }
-    static unsigned log_low_for(size_t total) { return small_launch(total) ? kLogLowSmall : kLogLow; }
+    unsigned log_low_for(size_t total) const { return small_launch(total) && !ef_small_off_ ? kLogLowSmall : kLogLow; }
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
     bool exit(const E* in, E* out, size_t n1, size_t count, hipStream_t s) {
