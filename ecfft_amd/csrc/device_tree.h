@@ -6,12 +6,14 @@
 // HBM layout ("Moiety precompute layout"): per tree T_m (m = 2e leaves), per moiety
 // parity s in {0,1}, structure-of-arrays tables holding only the half that parity uses:
 //   p0[s], p1[s], np0[s], dinv[s]   e-1 entries, stage k at offset e - 2*h_k   (h_k = e >> (k+1))
+//   c0t[s] = np0[s]*dinv[s]         likewise    (pair-split decompose of the latency regime: two independent products)
 //   w[s], winv[s]                   e entries   (normalisation weights of the parity's leaves)
 //   xe, w1x                         e entries   ENTER combine
 //   A1, B1, NB2, C1, D1, xie        e entries   EXIT pointwise steps with every inverse pre-fused
 // All tables are PLAIN residues; user data stays in the crate's Montgomery form (field_secp256k1.h).  The tables above are
-// stored as F::telem — for secp256k1 the pair (t, t*2^128 mod p) that the 12-word multiply wants — and are written by
-// to_tables() from plain temporaries; the reference's own tables (xnn, z*) stay plain F::elem arrays.
+// stored as F::telem — for secp256k1 the pair (t, t*2^128 mod p) that the 12-word multiply wants, for M31 the doubled constant
+// 2t (field_m31.h) — and are written by to_tables() from plain temporaries; the reference's own tables (xnn, z*) stay plain
+// F::elem arrays.  Below the level drivers: the sharded (multi-GPU) drivers extend_split / api_enter_split / api_exit_split.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>

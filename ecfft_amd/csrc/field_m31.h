@@ -8,7 +8,7 @@ namespace ecfft {
 
 struct M31 {
     using elem = uint32_t;
-    using telem = uint32_t;    // table constant as the butterflies read it (secp256k1 stores a pair, see field_secp256k1.h)
+    using telem = uint32_t;    // table constant as the butterflies read it: the DOUBLED residue 2t (see to_table below; secp256k1 stores a pair)
     static constexpr int kBytes = 4;
     static constexpr int kFieldId = 1;
     static constexpr uint32_t P = 0x7FFFFFFFu;
