@@ -16,6 +16,10 @@ pub mod ffi {
     pub struct EcfftCtx {
         _p: [u8; 0],
     }
+    #[repr(C)]
+    pub struct EcfftComm {
+        _p: [u8; 0],
+    }
     pub const OK: i32 = 0;
     pub const ERR_NOT_POW2: i32 = 1;
     pub const ERR_TREE_TOO_SMALL: i32 = 2;
@@ -53,6 +57,21 @@ pub mod ffi {
         pub fn ecfft_vanish(ctx: *mut EcfftCtx, domain: *const c_void, out: *mut c_void, nd: usize, mem: i32, stream: *mut c_void) -> i32;
         pub fn ecfft_degree(ctx: *mut EcfftCtx, evals: *const c_void, n: usize, mem: i32, stream: *mut c_void, degree: *mut usize) -> i32;
         pub fn ecfft_tree_table(ctx: *mut EcfftCtx, m: usize, which: i32, host_out: *mut c_void, cap: usize, count: *mut usize) -> i32;
+        pub fn ecfft_ctx_device_bytes(ctx: *const EcfftCtx) -> usize;
+        // one transform split over the GPUs of a node, one process per GPU (device pointers; see ecfft_hip.h)
+        pub fn ecfft_comm_get_unique_id(id_out: *mut c_void) -> i32; // ECFFT_COMM_ID_BYTES = 128
+        pub fn ecfft_comm_init_rank(id: *const c_void, world: i32, rank: i32, device: i32, out: *mut *mut EcfftComm) -> i32;
+        pub fn ecfft_comm_destroy(comm: *mut EcfftComm);
+        pub fn ecfft_comm_rank(comm: *const EcfftComm) -> i32;
+        pub fn ecfft_comm_world(comm: *const EcfftComm) -> i32;
+        pub fn ecfft_build_extend_shard(field: i32, e: usize, device: i32, world: i32, rank: i32, out: *mut *mut EcfftCtx) -> i32;
+        pub fn ecfft_extend_sharded(ctx: *mut EcfftCtx, comm: *mut EcfftComm, input: *const c_void, out: *mut c_void, e: usize, moiety: i32, stream: *mut c_void) -> i32;
+        pub fn ecfft_enter_sharded(ctx: *mut EcfftCtx, comm: *mut EcfftComm, coeffs: *const c_void, evals: *mut c_void, n: usize, stream: *mut c_void) -> i32;
+        pub fn ecfft_exit_sharded(ctx: *mut EcfftCtx, comm: *mut EcfftComm, evals: *const c_void, coeffs: *mut c_void, n: usize, stream: *mut c_void) -> i32;
+        pub fn ecfft_device_alloc(device: i32, bytes: usize, out: *mut *mut c_void) -> i32;
+        pub fn ecfft_device_free(ptr: *mut c_void) -> i32;
+        pub fn ecfft_device_copy(dst: *mut c_void, src: *const c_void, bytes: usize, kind: i32) -> i32; // 0 D2H, 1 H2D, 2 D2D
+        pub fn ecfft_device_sync(device: i32) -> i32;
     }
 }
 

@@ -157,6 +157,122 @@ public:
     }
 
     // ------------------------------------------------------------------------------------------
+    // SHARDED EXTEND context ("matrix tables shard the same way").  For ONE EXTEND of e evaluations split over
+    // P = 2^log_p GPUs a rank never touches most of T_2e: the cyclic stages k < log_p read only the stage-table entries
+    // i = i'*P + rank, the block-local stages k >= log_p only the last e/P entries of each stage table (pair distances <= e/2P),
+    // the 1/W and W scalings only the rank's e/P positions, and no other tree of the chain and none of the z tables is needed at
+    // all.  Everything a rank does need is pointwise in the point set (layers of f, isogeny denominators) plus batched
+    // inversions, so it is built directly — no full tree ever exists on any GPU: ~24 e/P table constants instead of the 28*(2e)
+    // elements of T_2e plus the 56e of the chain below it, and a build that is O(e/P) kernels' work instead of the chain's.
+    // Layout: trees_[log2(2e)] holds BIASED pointers (base - first_needed_index) for the block-local stage tables and for
+    // w / winv, so the single-GPU kernels index them unchanged; the cyclic entries live in compact arrays cyc_* laid out like the
+    // stage tables of a length-e/P vector (stage k at offset e/P - 2*h_k/P).
+    // ------------------------------------------------------------------------------------------
+    // HBM held by this context between calls: table arena + transform scratch (pooled temporaries of the algorithm wrappers
+    // and the host-call staging buffer come and go)
+    size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E); }
+    bool shard_mode() const { return shard_log_p_ != kNoShard; }
+    unsigned shard_log_p() const { return shard_log_p_; }
+    unsigned shard_rank() const { return shard_rank_; }
+    bool build_extend_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {
+        host_ = std::move(ht);
+        N_ = host_.n; L_ = ilog2(N_); device_ = device;
+        const size_t m = N_, e = m / 2, P = (size_t)1 << log_p, c = e >> log_p;
+        if (L_ < 2 || c < P || c < 2 || rank >= P) return false;
+        const unsigned le = L_ - 1;
+        ECFFT_HIP_TRY(hipSetDevice(device_));
+        hipStream_t s = nullptr;
+        // arena: den + per parity {5 local tables + 4 cyclic tables + w + winv} of c constants each + inner.  The point set f
+        // (all layers, 2N elements) is needed only while the tables are computed: a temporary, freed before returning.
+        size_t total = 64 + 2 * L_ + 2 * (11 * c + 64) * kTeElems + 4096;
+        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+        arena_cap_ = total; arena_used_ = 0;
+        E* fdev = temp(2 * N_);
+        ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
+        std::vector<E> den(2 * L_);
+        for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
+        den_ = take(2 * L_);
+        ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
+        trees_.assign(L_ + 1, Tree{});
+        Tree& T = trees_[L_];
+        T.m = m; T.e = e; T.log_m = L_;
+        const E* f = fdev; const size_t N = N_;
+        const size_t loc0 = e - 2 * (e >> (log_p + 1));          // first entry of the block-local stages: e - 2*h_{log_p} = e - c
+        const size_t nloc = c;                                   // entries [loc0, e) (the last one is padding, as in the full tables)
+        E* plain[2][4];                                          // local p0, p1, np0, dinv (plain) for the inner constants
+        for (int sg = 0; sg < 2; ++sg) {
+            // ---- block-local stages k >= log_p: the last c entries of every stage table
+            E *p0 = temp(nloc), *p1 = temp(nloc), *np0 = temp(nloc), *dinv = temp(nloc), *c0 = temp(nloc);
+            (void)hipMemsetAsync(p0 + (nloc - 1), 0, sizeof(E), s); (void)hipMemsetAsync(p1 + (nloc - 1), 0, sizeof(E), s);
+            (void)hipMemsetAsync(np0 + (nloc - 1), 0, sizeof(E), s); (void)hipMemsetAsync(dinv + (nloc - 1), 0, sizeof(E), s);
+            foreach_n(s, nloc - 1, [=] __device__(size_t gl) {
+                const size_t g = loc0 + gl, rem = e - g;         // same entry as build_tree's concatenated stage tables
+                unsigned k = 0; size_t h = e >> 1;
+                while (rem <= h) { h >>= 1; ++k; }
+                const size_t i = g - (e - 2 * h), lay = N >> k;
+                E a = f[lay + (2 * i + sg)], b = f[lay + (2 * i + sg + 2 * h)];
+                p0[gl] = a; p1[gl] = b; np0[gl] = F::neg(a); dinv[gl] = F::sub(b, a);
+            });
+            batch_inv(dinv, dinv, nloc - 1, s);
+            (void)hipMemsetAsync(c0 + (nloc - 1), 0, sizeof(E), s);
+            foreach_n(s, nloc - 1, [=] __device__(size_t gl) { c0[gl] = F::mul(np0[gl], dinv[gl]); });
+            plain[sg][0] = p0; plain[sg][1] = p1; plain[sg][2] = np0; plain[sg][3] = dinv;
+            T.p0[sg] = to_tables(p0, nloc, s) - loc0; T.p1[sg] = to_tables(p1, nloc, s) - loc0;
+            T.np0[sg] = to_tables(np0, nloc, s) - loc0; T.dinv[sg] = to_tables(dinv, nloc, s) - loc0;
+            T.c0t[sg] = to_tables(c0, nloc, s) - loc0;
+            // ---- cyclic stages k < log_p: entries i = i'*P + rank, compact, laid out like a length-c vector's stage tables
+            const size_t ncyc = c;
+            E *q0 = temp(ncyc), *q1 = temp(ncyc), *nq0 = temp(ncyc), *qd = temp(ncyc);
+            (void)hipMemsetAsync(q0, 0, ncyc * sizeof(E), s); (void)hipMemsetAsync(q1, 0, ncyc * sizeof(E), s);
+            (void)hipMemsetAsync(nq0, 0, ncyc * sizeof(E), s); (void)hipMemsetAsync(qd, 0, ncyc * sizeof(E), s);
+            for (unsigned k = 0; k < log_p; ++k) {
+                const size_t h = e >> (k + 1), hl = h >> log_p, offl = c - 2 * hl, lay = N >> k;
+                foreach_n(s, hl, [=] __device__(size_t il) {
+                    const size_t i = il * P + rank;
+                    E a = f[lay + (2 * i + sg)], b = f[lay + (2 * i + sg + 2 * h)];
+                    q0[offl + il] = a; q1[offl + il] = b; nq0[offl + il] = F::neg(a); qd[offl + il] = F::sub(b, a);
+                });
+            }
+            batch_inv(qd, qd, ncyc, s);                          // zero padding stays zero
+            cyc_[sg][0] = to_tables(nq0, ncyc, s); cyc_[sg][1] = to_tables(qd, ncyc, s);
+            cyc_[sg][2] = to_tables(q0, ncyc, s); cyc_[sg][3] = to_tables(q1, ncyc, s);
+            // ---- normalisation weights of the rank's c positions (DESIGN.md "Normalised butterflies")
+            E *w = temp(c), *wi = temp(c); const E* dn = den_; const size_t g0 = (size_t)rank * c;
+            foreach_n(s, c, [=] __device__(size_t il) {
+                const size_t j = 2 * (g0 + il) + sg;
+                E U = F::one(), C = F::one();
+                for (unsigned b = 0; b + 1 < le; ++b) {
+                    const size_t lsz = m >> b;
+                    E sb = f[(N >> b) + (j & (lsz - 1))];
+                    E V = F::mul_add(dn[2 * b + 1], sb, dn[2 * b]);
+                    C = F::mul(C, V);
+                    U = F::mul(F::sqr(U), C);
+                }
+                w[il] = U;
+            });
+            batch_inv(w, wi, c, s);
+            T.w[sg] = to_tables(w, c, s) - g0; T.winv[sg] = to_tables(wi, c, s) - g0;
+        }
+        for (int sg = 0; sg < 2; ++sg) {                         // merged innermost stage pair (build_tree): entries at index e-2
+            E* in = temp(2);
+            const size_t o = (e - 2) - loc0;
+            const E *sp0 = plain[sg][0] + o, *sdi = plain[sg][3] + o, *tp0 = plain[1 - sg][0] + o, *tp1 = plain[1 - sg][1] + o;
+            foreach_n(s, 1, [=] __device__(size_t) {
+                in[0] = F::mul(F::sub(tp0[0], sp0[0]), sdi[0]);
+                in[1] = F::mul(F::sub(tp1[0], sp0[0]), sdi[0]);
+            });
+            T.inner[sg] = to_tables(in, 2, s);
+        }
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) { fprintf(stderr, "ecfft: kernel launch failed: %s\n", hipGetErrorString(err)); return false; }
+        ECFFT_HIP_TRY(hipStreamSynchronize(s));
+        temps_free();
+        host_.f.clear(); host_.f.shrink_to_fit();                // the host copy of the point set is not needed either
+        shard_log_p_ = log_p; shard_rank_ = rank;
+        return true;
+    }
+
+    // ------------------------------------------------------------------------------------------
     // EXTEND core: all 2*log(e) normalised stages on `total` elements = count vectors of length
     // e = m/2 laid end to end, as a chain of fused passes:
     //     [column passes: top decompose stages, <= 4 per pass] -> row pass (every stage with
@@ -388,6 +504,8 @@ public:
         const unsigned r = (unsigned)(tr.rank - gbase);
         const int src = 1 - target;
         if (c < P || c < 2) return false;
+        const bool sh = shard_mode();                                          // tables of this context hold only this rank's share
+        if (sh && (log_p != shard_log_p_ || r != shard_rank_ || gbase != 0 || 2 * e != N_)) return false;
         {   // 1/W_src scaling + pack for block -> cyclic: element i goes to rank i mod P, slot i / P
             const TE* wi = T.winv[src]; const unsigned lp = log_p;
             foreach_n(s, c, [=] __device__(size_t i) { A[(i & (P - 1)) * cp + (i >> lp)] = F::canon(F::tmul(wi[g0 + i], in[i])); });
@@ -396,6 +514,12 @@ public:
         const size_t npairs = c / 2;
         for (unsigned k = 0; k < log_p; ++k) {                                 // cyclic shard: top decompose stages, table stride P / offset r
             size_t h = e >> (k + 1), off = e - 2 * h;
+            if (sh) {
+                const size_t offl = c - 2 * (h >> log_p);
+                ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                             B, (const TE*)(cyc_[src][0] + offl), (const TE*)(cyc_[src][1] + offl), ilog2(h >> log_p), npairs, 1u, 0u);
+                continue;
+            }
             ECFFT_LAUNCH(KC_DECOMPOSE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_decompose_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
                          B, T.np0[src] + off, T.dinv[src] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
         }
@@ -408,6 +532,12 @@ public:
         if (!exchange_group(tr, gbase, P, B, A, cp, s)) return false;          // A = cyclic shard
         for (unsigned k = log_p; k-- > 0;) {
             size_t h = e >> (k + 1), off = e - 2 * h;
+            if (sh) {
+                const size_t offl = c - 2 * (h >> log_p);
+                ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
+                             A, (const TE*)(cyc_[target][2] + offl), (const TE*)(cyc_[target][3] + offl), ilog2(h >> log_p), npairs, 1u, 0u);
+                continue;
+            }
             ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
                          A, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
         }
@@ -1147,6 +1277,9 @@ private:
     std::mutex mu_;
     mutable Profiler prof_;
     hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;
+    static constexpr unsigned kNoShard = ~0u;
+    unsigned shard_log_p_ = kNoShard, shard_rank_ = 0;      // sharded EXTEND context (build_extend_shard)
+    TE* cyc_[2][4] = {};                                    // per parity: np0, dinv, p0, p1 of the cyclic stages, compact
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

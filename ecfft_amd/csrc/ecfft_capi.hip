@@ -93,6 +93,10 @@ int guarded(Fn fn) {
 
 enum Op { OP_ENTER, OP_EXIT, OP_EXTEND };
 
+// a context made by ecfft_build_extend_shard holds one rank's share of ONE tree's EXTEND tables and nothing else: only
+// ecfft_extend_sharded (same world / rank / size), ecfft_tree_size, ecfft_field, ecfft_profile_* and ecfft_ctx_destroy accept it
+inline bool shard_only(const ecfft_ctx* c) { return c->field == ECFFT_FIELD_SECP256K1 ? c->secp->shard_mode() : c->m31->shard_mode(); }
+
 template <class F>
 int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, size_t len, size_t count, int moiety,
            int mem, void* stream) {
@@ -495,6 +499,47 @@ int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
     return ECFFT_OK;
 }
 
+int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!is_pow2(e) || !is_pow2((size_t)(world > 0 ? world : 0))) return ECFFT_ERR_NOT_POW2;
+    if (field != ECFFT_FIELD_SECP256K1 && field != ECFFT_FIELD_M31) return ECFFT_ERR_BAD_ARG;
+    if (world > 64 || rank < 0 || rank >= world) return ECFFT_ERR_BAD_ARG;
+    if (e / (size_t)world < 2 * (size_t)world) return ECFFT_ERR_BAD_ARG;     // same bound as ecfft_extend_sharded
+    const unsigned log_n = ilog2(e) + 1, log_p = ilog2((size_t)world);
+    if (field == ECFFT_FIELD_SECP256K1 && log_n >= 36) return ECFFT_ERR_TREE_TOO_LARGE;
+    if (field == ECFFT_FIELD_M31 && log_n > 28) return ECFFT_ERR_TREE_TOO_LARGE;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    std::unique_ptr<ecfft_ctx> c(new (std::nothrow) ecfft_ctx());
+    if (!c) return ECFFT_ERR_HIP;
+    c->field = field; c->device = device;
+    auto finish = [&](auto&& ht, auto& slot) {
+        using Chain = typename std::remove_reference<decltype(*slot)>::type;
+        slot.reset(new (std::nothrow) Chain());
+        if (!slot) return (int)ECFFT_ERR_HIP;
+        DeviceGuard dev(device);
+        if (!dev.ok) return (int)ECFFT_ERR_HIP;
+        return slot->build_extend_shard(std::move(ht), device, log_p, (unsigned)rank) ? (int)ECFFT_OK : (int)ECFFT_ERR_HIP;
+    };
+    int rc;
+    if (field == ECFFT_FIELD_SECP256K1) {
+        HostTree<Secp256k1> ht;
+        int r = build_host_tree<Secp256k1>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        rc = guarded([&] { return finish(std::move(ht), c->secp); });
+    } else {
+        HostTree<M31> ht;
+        int r = build_host_tree<M31>(log_n, ht);
+        if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
+        if (r) return ECFFT_ERR_BAD_ARG;
+        rc = guarded([&] { return finish(std::move(ht), c->m31); });
+    }
+    if (rc != ECFFT_OK) return rc;
+    *out = c.release();
+    return ECFFT_OK;
+}
+
 int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_num3, const void* map_den3, int device,
                      ecfft_ctx** out) {
     if (!out) return ECFFT_ERR_BAD_ARG;
@@ -578,62 +623,66 @@ size_t ecfft_tree_size(const ecfft_ctx* ctx) {
     return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->size() : ctx->m31->size();
 }
 int ecfft_field(const ecfft_ctx* ctx) { return ctx ? ctx->field : -1; }
+size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->device_bytes() : ctx->m31->device_bytes();
+}
 
 int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, 1, 0, mem, stream); });
 }
 int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, 1, 0, mem, stream); });
 }
 int ecfft_enter_many(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, size_t count, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_ENTER, coeffs, evals, n, count, 0, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_ENTER, coeffs, evals, n, count, 0, mem, stream); });
 }
 int ecfft_exit_many(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, size_t count, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXIT, evals, coeffs, n, count, 0, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_EXIT, evals, coeffs, n, count, 0, mem, stream); });
 }
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_op(ctx, *ctx->secp, OP_EXTEND, in, out, e, count, moiety, mem, stream)
                                                : run_op(ctx, *ctx->m31, OP_EXTEND, in, out, e, count, moiety, mem, stream); });
 }
 
 int ecfft_extend_top_cyclic(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, unsigned rank, int recombine, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream)
                                                : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, rank, recombine ? 1 : 0, mem, stream); });
 }
 int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, unsigned log_p, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_shard(ctx, *ctx->secp, buf, e, moiety, log_p, 0, 2, mem, stream)
                                                : run_shard(ctx, *ctx->m31, buf, e, moiety, log_p, 0, 2, mem, stream); });
 }
 
 int ecfft_mextend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_MEXTEND, in, nullptr, nullptr, out, e, count, moiety, mem, stream, nullptr); });
 }
 int ecfft_redc(ecfft_ctx* ctx, const void* evals, const void* a, void* out, size_t n, int moiety, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_REDC, evals, a, nullptr, out, n, 1, moiety, mem, stream, nullptr); });
 }
 int ecfft_modular_reduce(ecfft_ctx* ctx, const void* evals, const void* a, const void* c, void* out, size_t n, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_MOD, evals, a, c, out, n, 1, 0, mem, stream, nullptr); });
 }
 int ecfft_vanish(ecfft_ctx* ctx, const void* domain, void* out, size_t nd, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_VANISH, domain, nullptr, nullptr, out, nd, 1, 0, mem, stream, nullptr); });
 }
 int ecfft_degree(ecfft_ctx* ctx, const void* evals, size_t n, int mem, void* stream, size_t* degree) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ECFFT_DISPATCH_ALG(ALG_DEGREE, evals, nullptr, nullptr, nullptr, n, 1, 0, mem, stream, degree); });
 }
 
@@ -703,25 +752,25 @@ int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void*
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_EXTEND, in, out, e, moiety, stream); });
 }
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_ENTER, coeffs, evals, n, 0, stream)
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_ENTER, coeffs, evals, n, 0, stream); });
 }
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXIT, evals, coeffs, n, 0, stream)
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_EXIT, evals, coeffs, n, 0, stream); });
 }
 
 int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, size_t cnt, size_t m, int which, size_t t_off,
                     size_t t_stride, int mode, int mem, void* stream) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_table_fma(ctx, *ctx->secp, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream)
                                                : run_table_fma(ctx, *ctx->m31, out, x, y, cnt, m, which, t_off, t_stride, mode, mem, stream); });
 }
 
 int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count) {
-    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     DeviceGuard dev(ctx->device);
     if (!dev.ok) return ECFFT_ERR_HIP;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)

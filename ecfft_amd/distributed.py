@@ -81,14 +81,20 @@ class Comm:
         return Comm(h)
 
     @staticmethod
-    def callback(device=None):
+    def callback(device=None, world=None, rank=None, exchange=None):
         """communicator whose exchanges run over torch.distributed point-to-point calls staged through host memory (any
-        backend; the tests use gloo with several ranks on one GPU)"""
+        backend; the tests use gloo with several ranks on one GPU).  `exchange` (with `world` and `rank`) replaces that
+        transport by a caller-supplied function of the ecfft_exchange_fn signature (include/ecfft_hip.h)."""
         from . import fftree
         import numpy as np
         L = fftree.lib()
-        world, rank = dist.get_world_size(), dist.get_rank()
         device = torch.cuda.current_device() if device is None else device
+        if exchange is not None:
+            cb = fftree.EXCHANGE_FN(exchange)
+            h = ctypes.c_void_p()
+            fftree._check(L.ecfft_comm_init_callback(world, rank, device, cb, None, ctypes.byref(h)))
+            return Comm(h, keep=cb)
+        world, rank = dist.get_world_size(), dist.get_rank()
 
         def exchange(user, ns, sp, sptr, sb, nr, rp, rptr, rb, stream):
             try:

@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -101,6 +101,8 @@ def lib():
         L.ecfft_comm_stats_read.restype, L.ecfft_comm_stats_read.argtypes = ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
         L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+        L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
+        L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
         L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
         L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
@@ -141,6 +143,16 @@ class Field:
         """`F::build_fftree(n)`: None if n exceeds the curve's 2-adicity (src/lib.rs:62-64, src/ec.rs:513-515)."""
         h = ctypes.c_void_p()
         rc = lib().ecfft_build_fftree(self.id, n, device, ctypes.byref(h))
+        if rc == ERR_TREE_TOO_LARGE:
+            return None
+        _check(rc)
+        return FFTree(self, h, device)
+
+    def build_extend_shard(self, e, world, rank, device=0):
+        """Sharded EXTEND-only context (include/ecfft_hip.h ecfft_build_extend_shard): this rank's share of the tables of ONE
+        EXTEND of e evaluations over `world` GPUs; only `extend_sharded` works on it.  None if T_2e is too large for the curve."""
+        h = ctypes.c_void_p()
+        rc = lib().ecfft_build_extend_shard(self.id, e, device, world, rank, ctypes.byref(h))
         if rc == ERR_TREE_TOO_LARGE:
             return None
         _check(rc)
@@ -217,6 +229,11 @@ class FFTree:
         self._from_build = maps is None          # build_fftree: the maps are those of build_points(n)
         if maps is not None:
             self._num, self._den = maps
+
+    @property
+    def device_bytes(self):
+        """HBM the context holds between calls (tables + transform scratch)"""
+        return lib().ecfft_ctx_device_bytes(self._h)
 
     def __del__(self):
         try:

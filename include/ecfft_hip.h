@@ -76,6 +76,7 @@ void ecfft_ctx_destroy(ecfft_ctx* ctx);
 
 size_t ecfft_tree_size(const ecfft_ctx* ctx);   /* number of leaves of the top tree */
 int ecfft_field(const ecfft_ctx* ctx);
+size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch */
 
 /* coefficients -> evaluations on the leaves of T_n (n = len; any power of two <= tree size) */
 int ecfft_enter(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, int mem, void* stream);
@@ -140,6 +141,15 @@ int ecfft_comm_world(const ecfft_comm* comm);
 int ecfft_comm_stats_enable(ecfft_comm* comm, int on);
 int ecfft_comm_stats_read(ecfft_comm* comm, double* comm_ms, double* exchanges, double* bytes_sent);
 int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, void* stream);
+/* Sharded EXTEND-ONLY context: one rank's share of the tables ONE EXTEND of e evaluations over `world` GPUs reads (tree
+ * T_2e of build_fftree(2e); SURVEY 8(e) "matrix tables shard the same way").  Holds ~22 e/world table constants — the
+ * entries i = rank (mod world) of the stage tables for the cyclic stages, the last e/world entries for the block-local stages,
+ * the normalisation weights of the rank's positions — instead of the ~84 e elements of the full chain T_1 .. T_2e; no tree
+ * is ever materialised on any GPU.  Accepted by ecfft_extend_sharded only (same e, world and rank in the communicator, either
+ * moiety), plus ecfft_tree_size / ecfft_field / ecfft_ctx_device_bytes / ecfft_profile_* / ecfft_ctx_destroy; every other call returns
+ * ECFFT_ERR_BAD_ARG.  Results are bit-identical to ecfft_extend on a full context.  world = 2^k <= 64, e / world >= 2 * world;
+ * ECFFT_ERR_TREE_TOO_LARGE when T_2e exceeds the curve's 2-adicity, as ecfft_build_fftree(2e). */
+int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out);
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 

@@ -53,6 +53,13 @@ def main():
             want = tree.extend(full, moiety)
             ok = check(f"extend_sharded {moiety}", tree.extend_sharded(comm, mine.clone(), n, moiety), want) and ok
             ok = check(f"model extend {moiety}", D.extend_sharded(D.HipOps(tree), mine.clone(), n, moiety), want) and ok
+        # sharded EXTEND-only context: this rank's share of the tables only (ecfft_build_extend_shard), same results
+        shard = F.build_extend_shard(n, world, rank)
+        for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+            ok = check(f"shard-context extend {moiety}", shard.extend_sharded(comm, mine.clone(), n, moiety), tree.extend(full, moiety)) and ok
+        rc = ecfft_amd.lib().ecfft_enter(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, None)      # anything else is refused
+        ok = (rc == ecfft_amd.fftree.ERR_BAD_ARG) and ok
+        del shard
         # in place (in == out is allowed by the ABI): run through the raw call
         buf = mine.clone()
         ecfft_amd.fftree._check(ecfft_amd.lib().ecfft_extend_sharded(tree._h, comm._h, buf.data_ptr(), buf.data_ptr(), n, 1,

@@ -62,6 +62,9 @@ def test_sharded_transforms_over_rccl_single_rank():
             assert torch.equal(tree.extend_sharded(comm, x, n, moiety), tree.extend(x, moiety))
         assert torch.equal(tree.enter_sharded(comm, x, n), tree.enter(x))
         assert torch.equal(tree.exit_sharded(comm, x, n), tree.exit(x))
+        shard = ecfft_amd.FIELDS[field].build_extend_shard(n, 1, 0)             # EXTEND-only context, world = 1: the whole tables
+        for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+            assert torch.equal(shard.extend_sharded(comm, x, n, moiety), tree.extend(x, moiety))
     st = comm.stats()
     assert st["exchanges"] >= 16 and st["bytes_sent"] > 0 and st["comm_ms"] > 0      # 4 per EXTEND x 2 moieties x 2 fields
 
@@ -102,3 +105,73 @@ def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
         for r in range(P):
             full[r::P] = cyc[r]
         assert np.array_equal(full, expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("m31", 1 << 20, 3), ("secp256k1", 1 << 8, 2)])
+def test_extend_shard_context_on_one_gpu(field, e, log_p):
+    """ecfft_build_extend_shard: P sharded EXTEND-only contexts (each holding only its rank's table entries) driven as P
+    ranks of one process — a callback transport whose exchange is a barrier + device-to-device copies between the ranks'
+    buffers — == the single-GPU EXTEND of a full context, bit for bit; every other call on such a context is refused."""
+    import threading
+    import torch
+    import ecfft_amd
+    from ecfft_amd import distributed as D
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS[field]
+    P, c = 1 << log_p, e >> log_p
+    full_tree = F.build_fftree(2 * e)
+    rng = np.random.default_rng(5)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, e, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(e, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = {m: full_tree.extend(x, m) for m in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0)}
+    torch.cuda.synchronize()
+    board, bar, L = {}, threading.Barrier(P), FT.lib()
+
+    def make_exchange(rank):
+        def exchange(user, ns, speer, sptr, sbytes, nr, rpeer, rptr, rbytes, stream):
+            try:
+                L.ecfft_device_sync(0)
+                board[rank] = [(speer[i], sptr[i], sbytes[i]) for i in range(ns)]
+                bar.wait(timeout=60)
+                for i in range(nr):
+                    src = [q for q in board[rpeer[i]] if q[0] == rank]
+                    k = sum(1 for j in range(i) if rpeer[j] == rpeer[i])       # k-th message from that peer
+                    assert src[k][2] == rbytes[i]
+                    assert L.ecfft_device_copy(rptr[i], src[k][1], rbytes[i], 2) == 0
+                L.ecfft_device_sync(0)
+                bar.wait(timeout=60)
+                return 0
+            except Exception as ex:     # noqa: BLE001 — reported through the return code
+                print("exchange failed:", ex, flush=True)
+                bar.abort()
+                return 1
+        return exchange
+
+    got, errs = {}, []
+
+    def run(rank):
+        try:
+            comm = D.Comm.callback(world=P, rank=rank, device=0, exchange=make_exchange(rank))
+            shard = F.build_extend_shard(e, P, rank)
+            assert shard is not None and shard.n == 2 * e
+            mine = x[rank * c:(rank + 1) * c].clone()
+            for m in want:
+                got[(rank, int(m))] = shard.extend_sharded(comm, mine, e, m)
+            assert L.ecfft_extend(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, 1, 1, None) == FT.ERR_BAD_ARG
+            assert L.ecfft_enter_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), e, None) == FT.ERR_BAD_ARG
+        except Exception as ex:         # noqa: BLE001
+            errs.append((rank, repr(ex)))
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for m, w in want.items():
+        for r in range(P):
+            assert torch.equal(got[(r, int(m))], w[r * c:(r + 1) * c]), (field, e, log_p, r, m)

@@ -1,0 +1,20 @@
+"""HBM held by a full context (tables of the chain T_1..T_2e + scratch) vs a sharded EXTEND-only context
+(ecfft_build_extend_shard), and the build time of each.  python tools/shard_bytes.py [field log_e world ...]"""
+import sys
+import time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ecfft_amd  # noqa: E402
+
+cases = [("secp256k1", 22, 8), ("secp256k1", 22, 2), ("m31", 24, 8)]
+if len(sys.argv) > 3:
+    cases = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))]
+for field, log_e, world in cases:
+    F = ecfft_amd.FIELDS[field]
+    e = 1 << log_e
+    t = time.time(); full = F.build_fftree(2 * e); tf = time.time() - t
+    fb = full.device_bytes
+    del full
+    t = time.time(); sh = F.build_extend_shard(e, world, world - 1); ts = time.time() - t
+    sb = sh.device_bytes
+    print(f"{field} e=2^{log_e} world={world}: full context {fb / 2**20:.1f} MiB (build {tf:.2f} s)   shard context {sb / 2**20:.1f} MiB (build {ts:.2f} s)   ratio {fb / sb:.1f}x", flush=True)
