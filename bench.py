@@ -321,7 +321,12 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     from ecfft_amd import distributed as D
     e = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
-    tree = F.build_fftree(2 * e, device=local_rank)
+    # sharded EXTEND-only context: this rank's 1/world share of the tables of T_2e, nothing else (ecfft_build_extend_shard)
+    t_b = time.perf_counter()
+    tree = F.build_extend_shard(e, world, rank, device=local_rank)
+    if tree is None:
+        raise SystemExit("2e exceeds the curve's 2-adicity")
+    torch.cuda.synchronize(); build_s = time.perf_counter() - t_b
     c = e // world
     host = synth(args.field, e, 0x5EED0004)[rank * c:(rank + 1) * c]          # this rank's block of the same global vector
     x = torch.from_numpy(host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).cuda()
@@ -366,7 +371,9 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
                           "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
                           "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1} (BASELINE.json configs[3])", "e": e,
-                                     "parallelism": f"evaluation domain block-split over {world} GPU(s): ecfft_extend_sharded, 4 grouped ncclSend/ncclRecv exchanges per EXTEND"},
+                                     "parallelism": f"evaluation domain block-split over {world} GPU(s): ecfft_extend_sharded, 4 grouped ncclSend/ncclRecv exchanges per EXTEND",
+                                     "tables": "sharded: each GPU holds its 1/world share of T_2e's EXTEND tables (ecfft_build_extend_shard)",
+                                     "table_bytes_per_gpu": tree.device_bytes, "context_build_s": build_s},
                           "phases": phases, "round_trip_ok": ok}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()

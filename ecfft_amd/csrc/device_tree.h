@@ -182,9 +182,10 @@ public:
         const unsigned le = L_ - 1;
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
-        // arena: den + per parity {5 local tables + 4 cyclic tables + w + winv} of c constants each + inner.  The point set f
+        // arena: den + per parity {5 local tables + 4 cyclic tables + w + winv of the block and of the cyclic positions} of c
+        // constants each + inner.  The point set f
         // (all layers, 2N elements) is needed only while the tables are computed: a temporary, freed before returning.
-        size_t total = 64 + 2 * L_ + 2 * (11 * c + 64) * kTeElems + 4096;
+        size_t total = 64 + 2 * L_ + 2 * (13 * c + 64) * kTeElems + 4096;
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         E* fdev = temp(2 * N_);
@@ -252,6 +253,22 @@ public:
             });
             batch_inv(w, wi, c, s);
             T.w[sg] = to_tables(w, c, s) - g0; T.winv[sg] = to_tables(wi, c, s) - g0;
+            // ... and of its c CYCLIC positions il*P + rank (cyclic-in / cyclic-out calls)
+            E *wc = temp(c), *wci = temp(c);
+            foreach_n(s, c, [=] __device__(size_t il) {
+                const size_t j = 2 * (il * P + rank) + sg;
+                E U = F::one(), C = F::one();
+                for (unsigned b = 0; b + 1 < le; ++b) {
+                    const size_t lsz = m >> b;
+                    E sb = f[(N >> b) + (j & (lsz - 1))];
+                    E V = F::mul_add(dn[2 * b + 1], sb, dn[2 * b]);
+                    C = F::mul(C, V);
+                    U = F::mul(F::sqr(U), C);
+                }
+                wc[il] = U;
+            });
+            batch_inv(wc, wci, c, s);
+            cycw_[sg][0] = to_tables(wc, c, s); cycw_[sg][1] = to_tables(wci, c, s);
         }
         for (int sg = 0; sg < 2; ++sg) {                         // merged innermost stage pair (build_tree): entries at index e-2
             E* in = temp(2);
@@ -497,7 +514,10 @@ public:
     // [gbase, gbase + P) of `tr`: rank gbase + r holds positions [r*c, (r+1)*c), c = e/P.  in / out: this rank's shard (may
     // alias).  A, B: scratch of c elements each.  Stage k pairs (i, i + e >> (k+1)): stages k >= log_p are local in the block
     // distribution, stages k < log_p in the cyclic one (position j on rank j mod P).
-    bool extend_split(Transport& tr, int gbase, unsigned log_p, const E* in, E* out, size_t e, int target, hipStream_t s, E* A, E* B) const {
+    // cyc_in / cyc_out: the shard is CYCLIC instead (local j' <-> global position j'*P + r), which drops the first / last of the
+    // four exchanges — for callers that chain split EXTENDs or produce / consume the cyclic order anyway.
+    bool extend_split(Transport& tr, int gbase, unsigned log_p, const E* in, E* out, size_t e, int target, hipStream_t s, E* A, E* B,
+                      bool cyc_in = false, bool cyc_out = false) const {
         const unsigned log_m = ilog2(e) + 1;
         const Tree& T = trees_[log_m];
         const size_t P = (size_t)1 << log_p, c = e >> log_p, cp = c >> log_p, g0 = (size_t)(tr.rank - gbase) * c;
@@ -506,11 +526,16 @@ public:
         if (c < P || c < 2) return false;
         const bool sh = shard_mode();                                          // tables of this context hold only this rank's share
         if (sh && (log_p != shard_log_p_ || r != shard_rank_ || gbase != 0 || 2 * e != N_)) return false;
-        {   // 1/W_src scaling + pack for block -> cyclic: element i goes to rank i mod P, slot i / P
-            const TE* wi = T.winv[src]; const unsigned lp = log_p;
-            foreach_n(s, c, [=] __device__(size_t i) { A[(i & (P - 1)) * cp + (i >> lp)] = F::canon(F::tmul(wi[g0 + i], in[i])); });
+        if (cyc_in) {   // already cyclic: 1/W_src of positions j'*P + r
+            if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, B, in, (const TE*)cycw_[src][1], c - 1, c, 1u, 0u);
+            else ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, B, in, T.winv[src], c - 1, c, (uint32_t)P, r);
+        } else {
+            {   // 1/W_src scaling + pack for block -> cyclic: element i goes to rank i mod P, slot i / P
+                const TE* wi = T.winv[src]; const unsigned lp = log_p;
+                foreach_n(s, c, [=] __device__(size_t i) { A[(i & (P - 1)) * cp + (i >> lp)] = F::canon(F::tmul(wi[g0 + i], in[i])); });
+            }
+            if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;      // B = cyclic shard, ascending local index
         }
-        if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;          // B = cyclic shard, ascending local index
         const size_t npairs = c / 2;
         for (unsigned k = 0; k < log_p; ++k) {                                 // cyclic shard: top decompose stages, table stride P / offset r
             size_t h = e >> (k + 1), off = e - 2 * h;
@@ -541,6 +566,11 @@ public:
             ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
                          A, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
         }
+        if (cyc_out) {  // stay cyclic: W_target of positions j'*P + r
+            if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, (const TE*)cycw_[target][0], c - 1, c, 1u, 0u);
+            else ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, T.w[target], c - 1, c, (uint32_t)P, r);
+            return hipGetLastError() == hipSuccess;
+        }
         if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;          // B = chunks of the block shard
         {   // unpack + W_target scaling
             const TE* w = T.w[target]; const unsigned lp = log_p;
@@ -548,11 +578,11 @@ public:
         }
         return hipGetLastError() == hipSuccess;
     }
-    bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s) {
+    bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s, bool cyc_in = false, bool cyc_out = false) {
         const size_t P = (size_t)tr.world, c = e / P;
         if (P & (P - 1)) return false;
         E* A = temp(c); E* B = temp(c);
-        bool ok = extend_split(tr, 0, ilog2(P), in, out, e, target, s, A, B);
+        bool ok = extend_split(tr, 0, ilog2(P), in, out, e, target, s, A, B, cyc_in, cyc_out);
         temps_done();
         return ok;
     }
@@ -1280,6 +1310,7 @@ private:
     static constexpr unsigned kNoShard = ~0u;
     unsigned shard_log_p_ = kNoShard, shard_rank_ = 0;      // sharded EXTEND context (build_extend_shard)
     TE* cyc_[2][4] = {};                                    // per parity: np0, dinv, p0, p1 of the cyclic stages, compact
+    TE* cycw_[2][2] = {};                                   // per parity: w, winv of the rank's cyclic positions
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

@@ -436,7 +436,8 @@ int run_mul_ceiling(int device, int waves_per_simd, double* mul_per_s) {
 
 namespace {
 template <class F>
-int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const void* in, void* out, size_t len, int moiety, void* stream) {
+int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const void* in, void* out, size_t len, int moiety, void* stream,
+                int in_layout = ECFFT_LAYOUT_BLOCK, int out_layout = ECFFT_LAYOUT_BLOCK) {
     using E = typename F::elem;
     if (!in || !out || !comm || !comm->t) return ECFFT_ERR_BAD_ARG;
     if (!is_pow2(len)) return ECFFT_ERR_NOT_POW2;
@@ -447,6 +448,7 @@ int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const
     if (need_tree > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
     if (op == OP_EXTEND && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
     if (len / P < 2 * P) return ECFFT_ERR_BAD_ARG;                       // every rank needs at least 2P elements
+    if ((in_layout != ECFFT_LAYOUT_BLOCK && in_layout != ECFFT_LAYOUT_CYCLIC) || (out_layout != ECFFT_LAYOUT_BLOCK && out_layout != ECFFT_LAYOUT_CYCLIC)) return ECFFT_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     DeviceGuard dev(c->device);
     if (!dev.ok) return ECFFT_ERR_HIP;
@@ -455,7 +457,7 @@ int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const
     if (!scope.ok) return ECFFT_ERR_HIP;
     bool ok = false;
     switch (op) {
-        case OP_EXTEND: ok = ch.api_extend_split(tr, (const E*)in, (E*)out, len, moiety, s); break;
+        case OP_EXTEND: ok = ch.api_extend_split(tr, (const E*)in, (E*)out, len, moiety, s, in_layout == ECFFT_LAYOUT_CYCLIC, out_layout == ECFFT_LAYOUT_CYCLIC); break;
         case OP_ENTER: ok = ch.api_enter_split(tr, (const E*)in, (E*)out, len, s); break;
         case OP_EXIT: ok = ch.api_exit_split(tr, (const E*)in, (E*)out, len, s); break;
     }
@@ -750,6 +752,11 @@ int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void*
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXTEND, in, out, e, moiety, stream)
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_EXTEND, in, out, e, moiety, stream); });
+}
+int ecfft_extend_sharded_layout(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, int in_layout, int out_layout, void* stream) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXTEND, in, out, e, moiety, stream, in_layout, out_layout)
+                                                                    : run_sharded(ctx, *ctx->m31, comm, OP_EXTEND, in, out, e, moiety, stream, in_layout, out_layout); });
 }
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream) {
     if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;

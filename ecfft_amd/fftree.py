@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -101,6 +101,7 @@ def lib():
         L.ecfft_comm_stats_read.restype, L.ecfft_comm_stats_read.argtypes = ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
         L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+        L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
         L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
         L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
@@ -360,9 +361,12 @@ class FFTree:
         _check(fn(self._h, comm._h, x.data_ptr(), out.data_ptr(), length, *extra, stream))
         return out
 
-    def extend_sharded(self, comm, x_block, e, moiety):
-        """FFTree::extend of ONE length-e vector held block-distributed over the ranks of `comm` (C++ / RCCL path)"""
-        return self._sharded(lib().ecfft_extend_sharded, comm, x_block, e, int(moiety))
+    def extend_sharded(self, comm, x_block, e, moiety, cyclic_in=False, cyclic_out=False):
+        """FFTree::extend of ONE length-e vector held block-distributed over the ranks of `comm` (C++ / RCCL path);
+        cyclic_in / cyclic_out: the shard on that side is cyclic (local j' = global j' * world + rank), one exchange fewer each"""
+        if not (cyclic_in or cyclic_out):
+            return self._sharded(lib().ecfft_extend_sharded, comm, x_block, e, int(moiety))
+        return self._sharded(lib().ecfft_extend_sharded_layout, comm, x_block, e, int(moiety), int(cyclic_in), int(cyclic_out))
 
     def enter_sharded(self, comm, x_block, n):
         return self._sharded(lib().ecfft_enter_sharded, comm, x_block, n)

@@ -138,6 +138,11 @@ public:
 
     // ONE transform split over the ranks of `comm` (device pointers: this rank's block shard of len / world elements)
     void extend_sharded(const Comm& comm, const Elem* in, Elem* out, size_t e, Moiety m, void* stream) const { check(ecfft_extend_sharded(ctx_, comm.raw(), in, out, e, (int)m, stream)); }
+    // the same with a CYCLIC shard (local j' = global j' * world + rank) on either side: one exchange fewer per cyclic side
+    void extend_sharded_layout(const Comm& comm, const Elem* in, Elem* out, size_t e, Moiety m, bool cyclic_in, bool cyclic_out, void* stream) const {
+        check(ecfft_extend_sharded_layout(ctx_, comm.raw(), in, out, e, (int)m, cyclic_in ? ECFFT_LAYOUT_CYCLIC : ECFFT_LAYOUT_BLOCK,
+                                          cyclic_out ? ECFFT_LAYOUT_CYCLIC : ECFFT_LAYOUT_BLOCK, stream));
+    }
     void enter_sharded(const Comm& comm, const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter_sharded(ctx_, comm.raw(), coeffs, evals, n, stream)); }
     void exit_sharded(const Comm& comm, const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit_sharded(ctx_, comm.raw(), evals, coeffs, n, stream)); }
 

@@ -142,14 +142,21 @@ int ecfft_comm_stats_enable(ecfft_comm* comm, int on);
 int ecfft_comm_stats_read(ecfft_comm* comm, double* comm_ms, double* exchanges, double* bytes_sent);
 int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, void* stream);
 /* Sharded EXTEND-ONLY context: one rank's share of the tables ONE EXTEND of e evaluations over `world` GPUs reads (tree
- * T_2e of build_fftree(2e); SURVEY 8(e) "matrix tables shard the same way").  Holds ~22 e/world table constants — the
+ * T_2e of build_fftree(2e); SURVEY 8(e) "matrix tables shard the same way").  Holds 26 e/world table constants — the
  * entries i = rank (mod world) of the stage tables for the cyclic stages, the last e/world entries for the block-local stages,
  * the normalisation weights of the rank's positions — instead of the ~84 e elements of the full chain T_1 .. T_2e; no tree
- * is ever materialised on any GPU.  Accepted by ecfft_extend_sharded only (same e, world and rank in the communicator, either
+ * is ever materialised on any GPU.  Accepted by ecfft_extend_sharded / ecfft_extend_sharded_layout only (same e, world and rank in the communicator, either
  * moiety), plus ecfft_tree_size / ecfft_field / ecfft_ctx_device_bytes / ecfft_profile_* / ecfft_ctx_destroy; every other call returns
  * ECFFT_ERR_BAD_ARG.  Results are bit-identical to ecfft_extend on a full context.  world = 2^k <= 64, e / world >= 2 * world;
  * ECFFT_ERR_TREE_TOO_LARGE when T_2e exceeds the curve's 2-adicity, as ecfft_build_fftree(2e). */
 int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out);
+/* ecfft_extend_sharded with a choice of distribution for the rank's shard on each side.  ECFFT_LAYOUT_CYCLIC: local element j'
+ * is global position j' * world + rank.  A cyclic input saves the first of the four exchanges, a cyclic output the last one —
+ * for hosts that chain split EXTENDs or that produce / consume the cyclic order anyway.  (BLOCK, BLOCK) == ecfft_extend_sharded. */
+#define ECFFT_LAYOUT_BLOCK 0
+#define ECFFT_LAYOUT_CYCLIC 1
+int ecfft_extend_sharded_layout(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, int in_layout,
+                                int out_layout, void* stream);
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 

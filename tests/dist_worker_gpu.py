@@ -53,6 +53,17 @@ def main():
             want = tree.extend(full, moiety)
             ok = check(f"extend_sharded {moiety}", tree.extend_sharded(comm, mine.clone(), n, moiety), want) and ok
             ok = check(f"model extend {moiety}", D.extend_sharded(D.HipOps(tree), mine.clone(), n, moiety), want) and ok
+        # cyclic-in / cyclic-out variants on the full context (one exchange fewer each)
+        cyc = full[rank::world].contiguous()
+        for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+            want = tree.extend(full, moiety)
+            ok = check(f"extend cyclic-in {moiety}", tree.extend_sharded(comm, cyc, n, moiety, cyclic_in=True), want) and ok
+            got = tree.extend_sharded(comm, mine.clone(), n, moiety, cyclic_out=True)
+            if not torch.equal(got, want[rank::world]):
+                print(f"rank {rank}: {field} extend cyclic-out {moiety} MISMATCH", flush=True); ok = False
+            got = tree.extend_sharded(comm, cyc, n, moiety, cyclic_in=True, cyclic_out=True)
+            if not torch.equal(got, want[rank::world]):
+                print(f"rank {rank}: {field} extend cyclic-in-out {moiety} MISMATCH", flush=True); ok = False
         # sharded EXTEND-only context: this rank's share of the tables only (ecfft_build_extend_shard), same results
         shard = F.build_extend_shard(n, world, rank)
         for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):

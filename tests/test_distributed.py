@@ -161,6 +161,10 @@ def test_extend_shard_context_on_one_gpu(field, e, log_p):
             mine = x[rank * c:(rank + 1) * c].clone()
             for m in want:
                 got[(rank, int(m))] = shard.extend_sharded(comm, mine, e, m)
+                cyc = x[rank::P].contiguous()                                   # cyclic shard: local j' = global j' * P + rank
+                got[(rank, int(m), "cb")] = shard.extend_sharded(comm, cyc, e, m, cyclic_in=True)
+                got[(rank, int(m), "bc")] = shard.extend_sharded(comm, mine, e, m, cyclic_out=True)
+                got[(rank, int(m), "cc")] = shard.extend_sharded(comm, cyc, e, m, cyclic_in=True, cyclic_out=True)
             assert L.ecfft_extend(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, 1, 1, None) == FT.ERR_BAD_ARG
             assert L.ecfft_enter_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), e, None) == FT.ERR_BAD_ARG
         except Exception as ex:         # noqa: BLE001
@@ -175,3 +179,6 @@ def test_extend_shard_context_on_one_gpu(field, e, log_p):
     for m, w in want.items():
         for r in range(P):
             assert torch.equal(got[(r, int(m))], w[r * c:(r + 1) * c]), (field, e, log_p, r, m)
+            assert torch.equal(got[(r, int(m), "cb")], w[r * c:(r + 1) * c]), ("cyclic in", field, e, log_p, r, m)
+            assert torch.equal(got[(r, int(m), "bc")], w[r::P]), ("cyclic out", field, e, log_p, r, m)
+            assert torch.equal(got[(r, int(m), "cc")], w[r::P]), ("cyclic in and out", field, e, log_p, r, m)
