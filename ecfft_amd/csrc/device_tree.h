@@ -510,6 +510,34 @@ public:
         for (size_t q = 0; q < P; ++q) { snd[q] = {gbase + (int)q, from + q * piece, piece * sizeof(E)}; rcv[q] = {gbase + (int)q, to + q * piece, piece * sizeof(E)}; }
         return tr.exchange(snd, (int)P, rcv, (int)P, s);
     }
+    // Shard contexts keep the cyclic stages' table entries compact and laid out like the stage tables of a length-c vector, so the
+    // log_p cyclic stages are the TOP log_p stages of a "length-c EXTEND" on those tables: ONE fused column pass (k_stages_col)
+    // instead of log_p one-stage launches, with the 1/W or W scaling of a cyclic-in / cyclic-out call riding on its load / store.
+    // Returns false when the stage count does not fit one column tile (the caller then runs the one-stage kernels).
+    bool cyclic_stages_fused(const TE* ta, const TE* tb, const E* src, E* dst, size_t c, unsigned log_p, bool dec, const TE* ld_scale,
+                             const TE* st_scale, hipStream_t s) const {
+        const unsigned lc = ilog2(c);
+        unsigned log_ct = lc < kLogColTileMax ? lc : kLogColTileMax;
+        if (small_launch(c) && !ef_small_off_ && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
+        const unsigned R = log_p;
+        if (R == 0 || R > kColStages || R + 2 > log_ct) return false;
+        const unsigned log_cc = log_ct - R;
+        IoDesc<F> d = io_plain(src, dst);
+        if (ld_scale) { d.ld_mode = LD_SCALE; d.ld_tbl = ld_scale; }
+        if (st_scale) { d.st_mode = ST_SCALE; d.st_a = st_scale; }
+        const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
+        dim3 grid((unsigned)(c >> log_ct)); const size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_cc) << R);
+        double hsum = 0; for (unsigned k = 0; k < log_p; ++k) hsum += (double)(c >> (k + 1));
+        const double bytes = sizeof(E) * (2.0 * R * c + 4.0 * hsum);
+        if (dec) {
+            if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+            else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+        } else {
+            if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+            else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+        }
+        return true;
+    }
     // FFTree::extend (src/fftree.rs:123-126) of ONE vector of e evaluations held block-distributed by the P = 2^log_p ranks
     // [gbase, gbase + P) of `tr`: rank gbase + r holds positions [r*c, (r+1)*c), c = e/P.  in / out: this rank's shard (may
     // alias).  A, B: scratch of c elements each.  Stage k pairs (i, i + e >> (k+1)): stages k >= log_p are local in the block
@@ -526,7 +554,10 @@ public:
         if (c < P || c < 2) return false;
         const bool sh = shard_mode();                                          // tables of this context hold only this rank's share
         if (sh && (log_p != shard_log_p_ || r != shard_rank_ || gbase != 0 || 2 * e != N_)) return false;
-        if (cyc_in) {   // already cyclic: 1/W_src of positions j'*P + r
+        bool dec_done = false;
+        if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
+            dec_done = true;                                                   // 1/W + every cyclic decompose stage in one pass
+        } else if (cyc_in) {   // already cyclic: 1/W_src of positions j'*P + r
             if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, B, in, (const TE*)cycw_[src][1], c - 1, c, 1u, 0u);
             else ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, B, in, T.winv[src], c - 1, c, (uint32_t)P, r);
         } else {
@@ -537,7 +568,8 @@ public:
             if (!exchange_group(tr, gbase, P, A, B, cp, s)) return false;      // B = cyclic shard, ascending local index
         }
         const size_t npairs = c / 2;
-        for (unsigned k = 0; k < log_p; ++k) {                                 // cyclic shard: top decompose stages, table stride P / offset r
+        if (!dec_done && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], B, B, c, log_p, true, nullptr, nullptr, s)) dec_done = true;
+        for (unsigned k = 0; k < log_p && !dec_done; ++k) {                    // cyclic shard: top decompose stages, table stride P / offset r
             size_t h = e >> (k + 1), off = e - 2 * h;
             if (sh) {
                 const size_t offl = c - 2 * (h >> log_p);
@@ -555,6 +587,10 @@ public:
             extend_core(log_m, io, out, c, src, s, 0.0, 0.0, log_p);
         }
         if (!exchange_group(tr, gbase, P, B, A, cp, s)) return false;          // A = cyclic shard
+        if (sh && cyclic_stages_fused(cyc_[target][2], cyc_[target][3], A, cyc_out ? out : A, c, log_p, false, nullptr, cyc_out ? cycw_[target][0] : nullptr, s)) {
+            if (cyc_out) return hipGetLastError() == hipSuccess;               // every cyclic recombine stage + W in one pass
+            goto recombined;
+        }
         for (unsigned k = log_p; k-- > 0;) {
             size_t h = e >> (k + 1), off = e - 2 * h;
             if (sh) {
@@ -566,6 +602,7 @@ public:
             ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
                          A, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
         }
+    recombined:
         if (cyc_out) {  // stay cyclic: W_target of positions j'*P + r
             if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, (const TE*)cycw_[target][0], c - 1, c, 1u, 0u);
             else ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, T.w[target], c - 1, c, (uint32_t)P, r);

@@ -448,6 +448,8 @@ int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const
     if (need_tree > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
     if (op == OP_EXTEND && moiety != ECFFT_S0 && moiety != ECFFT_S1) return ECFFT_ERR_BAD_ARG;
     if (len / P < 2 * P) return ECFFT_ERR_BAD_ARG;                       // every rank needs at least 2P elements
+    if (ch.shard_mode() && (op != OP_EXTEND || 2 * len != ch.size() || P != ((size_t)1 << ch.shard_log_p()) || (unsigned)tr.rank != ch.shard_rank()))
+        return ECFFT_ERR_BAD_ARG;                                        // an EXTEND-only shard context serves exactly the split it was built for
     if ((in_layout != ECFFT_LAYOUT_BLOCK && in_layout != ECFFT_LAYOUT_CYCLIC) || (out_layout != ECFFT_LAYOUT_BLOCK && out_layout != ECFFT_LAYOUT_CYCLIC)) return ECFFT_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     DeviceGuard dev(c->device);

@@ -167,6 +167,8 @@ def test_extend_shard_context_on_one_gpu(field, e, log_p):
                 got[(rank, int(m), "cc")] = shard.extend_sharded(comm, cyc, e, m, cyclic_in=True, cyclic_out=True)
             assert L.ecfft_extend(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, 1, 1, None) == FT.ERR_BAD_ARG
             assert L.ecfft_enter_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), e, None) == FT.ERR_BAD_ARG
+            half = mine[: c // 2].clone()                                       # a different e than the context was built for
+            assert L.ecfft_extend_sharded(shard._h, comm._h, half.data_ptr(), half.data_ptr(), e // 2, 1, None) == FT.ERR_BAD_ARG
         except Exception as ex:         # noqa: BLE001
             errs.append((rank, repr(ex)))
             bar.abort()
