@@ -400,10 +400,14 @@ public:
                 unsigned nst = le - k_first;
                 double hsum = (double)((e >> k_first) - 1);                   // sum of h over the fused stages
                 double bytes = sizeof(E) * (2.0 * nst * 2.0 * total + 8.0 * hsum * tblw_) + extra;
-                if (log_tile == kLogTileMax + 1 && (sizeof(E) == 4 || ECFFT_CT_ALL))
+                // compile-time tiles of 4-byte fields run the register-resident stage engine, which works on chunks of 16 elements
+                // per thread: only valid when the default tile IS such a chunk (non-default ECFFT_LOG_TILE_BYTES / ECFFT_BLOCK_ROW
+                // builds fall back to the run-time-tile kernel)
+                constexpr bool ct_row = sizeof(E) == 4 ? ((size_t)1 << kLogTileMax) == (size_t)kBlockRow * 16 : (ECFFT_CT_ALL != 0);
+                if (log_tile == kLogTileMax + 1 && ct_row)
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
-                else if (log_tile == kLogTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
+                else if (log_tile == kLogTileMax && ct_row)   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
                 else
@@ -433,6 +437,7 @@ public:
     // when the number of spans is even and the halved grid still fills the chip twice over
     static unsigned pair_spans(size_t total, unsigned le, unsigned ka, unsigned log_ct, const IoDesc<F>& d) {
         if (sizeof(E) != 4 || ECFFT_COL_PAD != 0 || log_ct != kLogColTileMax) return 0;
+        if (((size_t)1 << log_ct) != (size_t)kBlockLds * 16) return 0;    // the kernels' vector path (kFast) exists for 16 elements per thread only
         // the paired form exists only on the kernels' 16-byte vector path: every buffer the pass touches must be 16-byte aligned
         // (user buffers may be only element-aligned) and the operator must be one the vector path implements
         auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
