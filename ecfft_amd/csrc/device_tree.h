@@ -171,37 +171,35 @@ public:
     // HBM held by this context between calls: table arena + transform scratch (pooled temporaries of the algorithm wrappers
     // and the host-call staging buffer come and go)
     size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E); }
-    bool shard_mode() const { return shard_log_p_ != kNoShard; }
+    enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2 };
+    int shard_kind() const { return shard_kind_; }
+    bool shard_mode() const { return shard_kind_ != kShardNone; }
     unsigned shard_log_p() const { return shard_log_p_; }
     unsigned shard_rank() const { return shard_rank_; }
-    bool build_extend_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {
-        host_ = std::move(ht);
-        N_ = host_.n; L_ = ilog2(N_); device_ = device;
-        const size_t m = N_, e = m / 2, P = (size_t)1 << log_p, c = e >> log_p;
-        if (L_ < 2 || c < P || c < 2 || rank >= P) return false;
-        const unsigned le = L_ - 1;
-        ECFFT_HIP_TRY(hipSetDevice(device_));
-        hipStream_t s = nullptr;
-        // arena: den + per parity {5 local tables + 4 cyclic tables + w + winv of the block and of the cyclic positions} of c
-        // constants each + inner.  The point set f
-        // (all layers, 2N elements) is needed only while the tables are computed: a temporary, freed before returning.
-        size_t total = 64 + 2 * L_ + 2 * (13 * c + 64) * kTeElems + 4096;
-        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
-        arena_cap_ = total; arena_used_ = 0;
-        E* fdev = temp(2 * N_);
-        ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
-        std::vector<E> den(2 * L_);
-        for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
-        den_ = take(2 * L_);
-        ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
-        trees_.assign(L_ + 1, Tree{});
-        Tree& T = trees_[L_];
-        T.m = m; T.e = e; T.log_m = L_;
-        const E* f = fdev; const size_t N = N_;
+    // One rank's share of the EXTEND tables of the tree with 2^log_m leaves (a tree of the chain of T_N: its layer k is every
+    // (N/m)-th point of the top tree's layer k) for a split over 2^log_p ranks; f = the device copy of the point set.
+    struct ShardSet {
+        bool valid = false; unsigned log_p = 0, rank = 0;
+        TE* cyc[2][4] = {};      // per parity: np0, dinv, p0, p1 of the cyclic stages, compact
+        TE* cycw[2][2] = {};     // per parity: w, winv of the rank's cyclic positions
+    };
+    // only_target = 0 / 1: keep only what EXTENDs towards that moiety read (decompose-side tables of the source parity,
+    // recombine-side tables of the target parity): half the constants; -1: both directions
+    static size_t shard_set_elems(size_t c, int only_target = -1) { return (only_target < 0 ? 2 : 1) * (13 * c + 128) * kTeElems + 64; }
+    bool build_shard_set(unsigned log_m, unsigned log_p, unsigned rank, const E* f, hipStream_t s, int only_target = -1) {
+        const size_t m = (size_t)1 << log_m, e = m / 2, P = (size_t)1 << log_p, c = e >> log_p, stride = N_ / m;
+        if (log_m < 2 || c < P || c < 2 || rank >= P) return false;
+        const unsigned le = log_m - 1;
+        Tree& T = trees_[log_m]; ShardSet& S = sets_[log_m];
+        T.m = m; T.e = e; T.log_m = log_m;
+        S.valid = true; S.log_p = log_p; S.rank = rank;
+        const size_t N = N_;
         const size_t loc0 = e - 2 * (e >> (log_p + 1));          // first entry of the block-local stages: e - 2*h_{log_p} = e - c
         const size_t nloc = c;                                   // entries [loc0, e) (the last one is padding, as in the full tables)
         E* plain[2][4];                                          // local p0, p1, np0, dinv (plain) for the inner constants
         for (int sg = 0; sg < 2; ++sg) {
+            const bool dec = only_target < 0 || sg == 1 - only_target;       // this parity is an EXTEND source
+            const bool rec = only_target < 0 || sg == only_target;           // ... an EXTEND target
             // ---- block-local stages k >= log_p: the last c entries of every stage table
             E *p0 = temp(nloc), *p1 = temp(nloc), *np0 = temp(nloc), *dinv = temp(nloc), *c0 = temp(nloc);
             (void)hipMemsetAsync(p0 + (nloc - 1), 0, sizeof(E), s); (void)hipMemsetAsync(p1 + (nloc - 1), 0, sizeof(E), s);
@@ -211,16 +209,15 @@ public:
                 unsigned k = 0; size_t h = e >> 1;
                 while (rem <= h) { h >>= 1; ++k; }
                 const size_t i = g - (e - 2 * h), lay = N >> k;
-                E a = f[lay + (2 * i + sg)], b = f[lay + (2 * i + sg + 2 * h)];
+                E a = f[lay + (2 * i + sg) * stride], b = f[lay + (2 * i + sg + 2 * h) * stride];
                 p0[gl] = a; p1[gl] = b; np0[gl] = F::neg(a); dinv[gl] = F::sub(b, a);
             });
             batch_inv(dinv, dinv, nloc - 1, s);
             (void)hipMemsetAsync(c0 + (nloc - 1), 0, sizeof(E), s);
             foreach_n(s, nloc - 1, [=] __device__(size_t gl) { c0[gl] = F::mul(np0[gl], dinv[gl]); });
             plain[sg][0] = p0; plain[sg][1] = p1; plain[sg][2] = np0; plain[sg][3] = dinv;
-            T.p0[sg] = to_tables(p0, nloc, s) - loc0; T.p1[sg] = to_tables(p1, nloc, s) - loc0;
-            T.np0[sg] = to_tables(np0, nloc, s) - loc0; T.dinv[sg] = to_tables(dinv, nloc, s) - loc0;
-            T.c0t[sg] = to_tables(c0, nloc, s) - loc0;
+            if (rec) { T.p0[sg] = to_tables(p0, nloc, s) - loc0; T.p1[sg] = to_tables(p1, nloc, s) - loc0; }
+            if (dec) { T.np0[sg] = to_tables(np0, nloc, s) - loc0; T.dinv[sg] = to_tables(dinv, nloc, s) - loc0; T.c0t[sg] = to_tables(c0, nloc, s) - loc0; }
             // ---- cyclic stages k < log_p: entries i = i'*P + rank, compact, laid out like a length-c vector's stage tables
             const size_t ncyc = c;
             E *q0 = temp(ncyc), *q1 = temp(ncyc), *nq0 = temp(ncyc), *qd = temp(ncyc);
@@ -230,47 +227,37 @@ public:
                 const size_t h = e >> (k + 1), hl = h >> log_p, offl = c - 2 * hl, lay = N >> k;
                 foreach_n(s, hl, [=] __device__(size_t il) {
                     const size_t i = il * P + rank;
-                    E a = f[lay + (2 * i + sg)], b = f[lay + (2 * i + sg + 2 * h)];
+                    E a = f[lay + (2 * i + sg) * stride], b = f[lay + (2 * i + sg + 2 * h) * stride];
                     q0[offl + il] = a; q1[offl + il] = b; nq0[offl + il] = F::neg(a); qd[offl + il] = F::sub(b, a);
                 });
             }
             batch_inv(qd, qd, ncyc, s);                          // zero padding stays zero
-            cyc_[sg][0] = to_tables(nq0, ncyc, s); cyc_[sg][1] = to_tables(qd, ncyc, s);
-            cyc_[sg][2] = to_tables(q0, ncyc, s); cyc_[sg][3] = to_tables(q1, ncyc, s);
-            // ---- normalisation weights of the rank's c positions (DESIGN.md "Normalised butterflies")
-            E *w = temp(c), *wi = temp(c); const E* dn = den_; const size_t g0 = (size_t)rank * c;
-            foreach_n(s, c, [=] __device__(size_t il) {
-                const size_t j = 2 * (g0 + il) + sg;
-                E U = F::one(), C = F::one();
-                for (unsigned b = 0; b + 1 < le; ++b) {
-                    const size_t lsz = m >> b;
-                    E sb = f[(N >> b) + (j & (lsz - 1))];
-                    E V = F::mul_add(dn[2 * b + 1], sb, dn[2 * b]);
-                    C = F::mul(C, V);
-                    U = F::mul(F::sqr(U), C);
-                }
-                w[il] = U;
-            });
-            batch_inv(w, wi, c, s);
-            T.w[sg] = to_tables(w, c, s) - g0; T.winv[sg] = to_tables(wi, c, s) - g0;
-            // ... and of its c CYCLIC positions il*P + rank (cyclic-in / cyclic-out calls)
-            E *wc = temp(c), *wci = temp(c);
-            foreach_n(s, c, [=] __device__(size_t il) {
-                const size_t j = 2 * (il * P + rank) + sg;
-                E U = F::one(), C = F::one();
-                for (unsigned b = 0; b + 1 < le; ++b) {
-                    const size_t lsz = m >> b;
-                    E sb = f[(N >> b) + (j & (lsz - 1))];
-                    E V = F::mul_add(dn[2 * b + 1], sb, dn[2 * b]);
-                    C = F::mul(C, V);
-                    U = F::mul(F::sqr(U), C);
-                }
-                wc[il] = U;
-            });
-            batch_inv(wc, wci, c, s);
-            cycw_[sg][0] = to_tables(wc, c, s); cycw_[sg][1] = to_tables(wci, c, s);
+            if (dec) { S.cyc[sg][0] = to_tables(nq0, ncyc, s); S.cyc[sg][1] = to_tables(qd, ncyc, s); }
+            if (rec) { S.cyc[sg][2] = to_tables(q0, ncyc, s); S.cyc[sg][3] = to_tables(q1, ncyc, s); }
+            // ---- normalisation weights (DESIGN.md "Normalised butterflies") of the rank's c BLOCK positions g0 + il and of its
+            // c CYCLIC positions il*P + rank (cyclic-in / cyclic-out calls)
+            const E* dn = den_; const size_t g0 = (size_t)rank * c;
+            for (int cyc = 0; cyc < 2; ++cyc) {
+                E *w = temp(c), *wi = temp(c);
+                foreach_n(s, c, [=] __device__(size_t il) {
+                    const size_t j = 2 * (cyc ? il * P + rank : g0 + il) + sg;
+                    E U = F::one(), C = F::one();
+                    for (unsigned b = 0; b + 1 < le; ++b) {
+                        const size_t lsz = m >> b;
+                        E sb = f[(N >> b) + (j & (lsz - 1)) * stride];
+                        E V = F::mul_add(dn[2 * b + 1], sb, dn[2 * b]);
+                        C = F::mul(C, V);
+                        U = F::mul(F::sqr(U), C);
+                    }
+                    w[il] = U;
+                });
+                batch_inv(w, wi, c, s);
+                if (cyc) { if (rec) S.cycw[sg][0] = to_tables(w, c, s); if (dec) S.cycw[sg][1] = to_tables(wi, c, s); }
+                else { if (rec) T.w[sg] = to_tables(w, c, s) - g0; if (dec) T.winv[sg] = to_tables(wi, c, s) - g0; }
+            }
         }
         for (int sg = 0; sg < 2; ++sg) {                         // merged innermost stage pair (build_tree): entries at index e-2
+            if (only_target >= 0 && sg != 1 - only_target) continue;   // indexed by the SOURCE parity
             E* in = temp(2);
             const size_t o = (e - 2) - loc0;
             const E *sp0 = plain[sg][0] + o, *sdi = plain[sg][3] + o, *tp0 = plain[1 - sg][0] + o, *tp1 = plain[1 - sg][1] + o;
@@ -280,12 +267,90 @@ public:
             });
             T.inner[sg] = to_tables(in, 2, s);
         }
+        return hipGetLastError() == hipSuccess;
+    }
+    bool upload_points(E*& fdev, hipStream_t s) {               // the caller hipFree()s fdev
+        ECFFT_HIP_TRY(hipMalloc(&fdev, 2 * N_ * sizeof(E)));
+        ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
+        std::vector<E> den(2 * (L_ ? L_ : 1));
+        for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
+        den_ = take(2 * (L_ ? L_ : 1));
+        ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
+        ECFFT_HIP_TRY(hipStreamSynchronize(s));                  // `den` is a stack vector
+        return true;
+    }
+    bool build_extend_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {
+        host_ = std::move(ht);
+        N_ = host_.n; L_ = ilog2(N_); device_ = device;
+        const size_t c = (N_ / 2) >> log_p;
+        if (L_ < 2 || c < ((size_t)1 << log_p) || c < 2 || rank >= ((size_t)1 << log_p)) return false;
+        ECFFT_HIP_TRY(hipSetDevice(device_));
+        hipStream_t s = nullptr;
+        // arena: den + per parity {5 local tables + 4 cyclic tables + w + winv of the block and of the cyclic positions} of c
+        // constants each + inner.  The point set f (all layers, 2N elements) is needed only while the tables are computed: a
+        // temporary, freed before returning.
+        size_t total = 64 + 2 * L_ + shard_set_elems(c) + 4096;
+        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+        arena_cap_ = total; arena_used_ = 0;
+        E* fdev = nullptr;
+        if (!upload_points(fdev, s)) return false;
+        trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
+        const bool built = build_shard_set(L_, log_p, rank, fdev, s);
+        const bool drained = hipStreamSynchronize(s) == hipSuccess;
+        (void)hipFree(fdev);
+        temps_free();
+        if (!built || !drained) { fprintf(stderr, "ecfft: shard table build failed\n"); return false; }
+        host_.f.clear(); host_.f.shrink_to_fit();                // the host copy of the point set is not needed either
+        shard_kind_ = kShardExtend; shard_log_p_ = log_p; shard_rank_ = rank;
+        return true;
+    }
+
+    // SHARDED ENTER context for ONE ENTER of n coefficients split over P = 2^log_p GPUs (api_enter_split): the full chain
+    // T_1 .. T_c, c = n/P, for the rank-local low levels (every rank runs the same ENTER of its chunk on T_c), and for each of
+    // the log P top levels m = c*Q only the rank's share of T_m: the EXTEND tables of the split over its half-group (a ShardSet
+    // with 2^log_p' = Q/2, rank' = rank mod Q/2; Q = 2 is a local EXTEND = the "split" over one rank) and the c entries of
+    // xnn_s = leaf^(m/2) its combine step reads.  All pointwise in the point set: no tree above T_c is materialised anywhere.
+    // ~56 c elements for the chain + 13 c constants per top level (ENTER only extends towards S1) instead of 56 n.
+    bool build_enter_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {
+        host_ = std::move(ht);
+        N_ = host_.n; L_ = ilog2(N_); device_ = device;
+        const size_t P = (size_t)1 << log_p, c = N_ >> log_p;
+        if (log_p == 0 || L_ < 2 || c < 2 * P || rank >= P) return false;
+        const unsigned lc = ilog2(c);
+        ECFFT_HIP_TRY(hipSetDevice(device_));
+        hipStream_t s = nullptr;
+        size_t total = 64 + 2 * L_ + 4096;
+        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
+        total += log_p * (shard_set_elems(c, 1) + c + 64);
+        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+        arena_cap_ = total; arena_used_ = 0;
+        E* fdev = nullptr;
+        if (!upload_points(fdev, s)) return false;
+        struct Free { E* p; ~Free() { (void)hipFree(p); } } free_f{fdev};
+        f_ = fdev;                                               // build_tree reads f_; reset below
+        if (!ensure_scratch(c)) return false;
+        trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
+        for (unsigned l = 0; l <= lc; ++l) { if (!build_tree(l, s)) { f_ = nullptr; return false; } }
+        for (size_t Q = 2; Q <= P; Q *= 2) {
+            const size_t half = Q / 2, m = c * Q, hc = c / 2;
+            const unsigned lm = ilog2(m);
+            const size_t a = rank % Q, ap = a / 2, b = a % 2, i0 = ap * c + b * hc, stride = N_ / m;
+            if (!build_shard_set(lm, ilog2(half), (unsigned)(a % half), fdev, s, 1)) { f_ = nullptr; return false; }   // ENTER extends towards S1 only
+            E* x = take(c); const E* f = fdev; const size_t N = N_; const uint64_t ex = m / 2;
+            foreach_n(s, c, [=] __device__(size_t j) { x[j] = F::pow_u64(f[N + (2 * i0 + j) * stride], ex); });
+            trees_[lm].xnn = x - 2 * i0;
+            if (hipStreamSynchronize(s) != hipSuccess) { f_ = nullptr; return false; }
+            temps_free();
+        }
+        f_ = nullptr;
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) { fprintf(stderr, "ecfft: kernel launch failed: %s\n", hipGetErrorString(err)); return false; }
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
         temps_free();
-        host_.f.clear(); host_.f.shrink_to_fit();                // the host copy of the point set is not needed either
-        shard_log_p_ = log_p; shard_rank_ = rank;
+        host_.f.clear(); host_.f.shrink_to_fit();
+        ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
+        ECFFT_HIP_TRY(hipMemcpy(d_trees_, trees_.data(), (L_ + 1) * sizeof(Tree), hipMemcpyHostToDevice));
+        shard_kind_ = kShardEnter; shard_log_p_ = log_p; shard_rank_ = rank;
         return true;
     }
 
@@ -558,7 +623,10 @@ public:
         const int src = 1 - target;
         if (c < P || c < 2) return false;
         const bool sh = shard_mode();                                          // tables of this context hold only this rank's share
-        if (sh && (log_p != shard_log_p_ || r != shard_rank_ || gbase != 0 || 2 * e != N_)) return false;
+        if (sh && (log_m >= sets_.size() || !sets_[log_m].valid || sets_[log_m].log_p != log_p || sets_[log_m].rank != r)) return false;
+        static const ShardSet kNoSet{};
+        const ShardSet& SS = sh ? sets_[log_m] : kNoSet;
+        TE* const (&cyc_)[2][4] = SS.cyc; TE* const (&cycw_)[2][2] = SS.cycw;
         bool dec_done = false;
         if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
             dec_done = true;                                                   // 1/W + every cyclic decompose stage in one pass
@@ -1349,10 +1417,9 @@ private:
     std::mutex mu_;
     mutable Profiler prof_;
     hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;
-    static constexpr unsigned kNoShard = ~0u;
-    unsigned shard_log_p_ = kNoShard, shard_rank_ = 0;      // sharded EXTEND context (build_extend_shard)
-    TE* cyc_[2][4] = {};                                    // per parity: np0, dinv, p0, p1 of the cyclic stages, compact
-    TE* cycw_[2][2] = {};                                   // per parity: w, winv of the rank's cyclic positions
+    int shard_kind_ = kShardNone;                           // sharded EXTEND-only / ENTER-only context (build_*_shard)
+    unsigned shard_log_p_ = 0, shard_rank_ = 0;
+    std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -102,6 +102,7 @@ def lib():
         L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
         L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
         L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
+        L.ecfft_build_enter_shard.restype, L.ecfft_build_enter_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
         L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
@@ -154,6 +155,16 @@ class Field:
         EXTEND of e evaluations over `world` GPUs; only `extend_sharded` works on it.  None if T_2e is too large for the curve."""
         h = ctypes.c_void_p()
         rc = lib().ecfft_build_extend_shard(self.id, e, device, world, rank, ctypes.byref(h))
+        if rc == ERR_TREE_TOO_LARGE:
+            return None
+        _check(rc)
+        return FFTree(self, h, device)
+
+    def build_enter_shard(self, n, world, rank, device=0):
+        """Sharded ENTER-only context (ecfft_build_enter_shard): the chain up to n/world plus this rank's share of the top
+        log2(world) trees; only `enter_sharded` works on it.  None if T_n is too large for the curve."""
+        h = ctypes.c_void_p()
+        rc = lib().ecfft_build_enter_shard(self.id, n, device, world, rank, ctypes.byref(h))
         if rc == ERR_TREE_TOO_LARGE:
             return None
         _check(rc)

@@ -150,6 +150,14 @@ int ecfft_extend_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void*
  * ECFFT_ERR_BAD_ARG.  Results are bit-identical to ecfft_extend on a full context.  world = 2^k <= 64, e / world >= 2 * world;
  * ECFFT_ERR_TREE_TOO_LARGE when T_2e exceeds the curve's 2-adicity, as ecfft_build_fftree(2e). */
 int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out);
+/* Sharded ENTER-ONLY context for ONE ENTER of n coefficients over `world` GPUs (ecfft_enter_sharded): the full chain T_1 .. T_c,
+ * c = n / world, for the rank-local low levels, and for each of the log2(world) top levels only the rank's share of that tree —
+ * the EXTEND tables of the split over its half-group and the c entries of xnn_s its combine step reads (src/fftree.rs:155-159).
+ * All of it is pointwise in the point set: no tree above T_c is materialised on any GPU (~1/world of a full context's HBM), so
+ * an ENTER can be larger than one GPU's table capacity.  Accepted by ecfft_enter_sharded only (same n, world and rank), plus
+ * the informational calls listed above.  world = 2^k, 2 <= world <= 64, n / world >= 2 * world.  (A sharded EXIT context would
+ * need z0_inv_s1 / z0z0_rem_xnn_s ranges of the top trees, i.e. a distributed table build: not provided.) */
+int ecfft_build_enter_shard(int field, size_t n, int device, int world, int rank, ecfft_ctx** out);
 /* ecfft_extend_sharded with a choice of distribution for the rank's shard on each side.  ECFFT_LAYOUT_CYCLIC: local element j'
  * is global position j' * world + rank.  A cyclic input saves the first of the four exchanges, a cyclic output the last one —
  * for hosts that chain split EXTENDs or that produce / consume the cyclic order anyway.  (BLOCK, BLOCK) == ecfft_extend_sharded. */

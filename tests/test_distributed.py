@@ -184,3 +184,88 @@ def test_extend_shard_context_on_one_gpu(field, e, log_p):
             assert torch.equal(got[(r, int(m), "cb")], w[r * c:(r + 1) * c]), ("cyclic in", field, e, log_p, r, m)
             assert torch.equal(got[(r, int(m), "bc")], w[r::P]), ("cyclic out", field, e, log_p, r, m)
             assert torch.equal(got[(r, int(m), "cc")], w[r::P]), ("cyclic in and out", field, e, log_p, r, m)
+
+
+def _thread_ranks(P, body):
+    """run body(rank, make_comm) on P threads; make_comm() gives a callback communicator whose exchange is a barrier +
+    device-to-device copies between the ranks' buffers (all ranks share cuda:0)"""
+    import threading
+    from ecfft_amd import distributed as D
+    from ecfft_amd import fftree as FT
+    board, bar, L = {}, threading.Barrier(P), FT.lib()
+
+    def make_exchange(rank):
+        def exchange(user, ns, speer, sptr, sbytes, nr, rpeer, rptr, rbytes, stream):
+            try:
+                L.ecfft_device_sync(0)
+                board[rank] = [(speer[i], sptr[i], sbytes[i]) for i in range(ns)]
+                bar.wait(timeout=120)
+                for i in range(nr):
+                    src = [q for q in board[rpeer[i]] if q[0] == rank]
+                    k = sum(1 for j in range(i) if rpeer[j] == rpeer[i])
+                    assert src[k][2] == rbytes[i]
+                    assert L.ecfft_device_copy(rptr[i], src[k][1], rbytes[i], 2) == 0
+                L.ecfft_device_sync(0)
+                bar.wait(timeout=120)
+                return 0
+            except Exception as ex:     # noqa: BLE001 — reported through the return code
+                print("exchange failed:", ex, flush=True)
+                bar.abort()
+                return 1
+        return exchange
+
+    errs = []
+
+    def run(rank):
+        try:
+            body(rank, lambda: D.Comm.callback(world=P, rank=rank, device=0, exchange=make_exchange(rank)))
+        except Exception as ex:         # noqa: BLE001
+            import traceback
+            errs.append((rank, repr(ex), traceback.format_exc()))
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8)])
+def test_enter_shard_context_on_one_gpu(field, n, P):
+    """ecfft_build_enter_shard: P sharded ENTER-only contexts (chain up to n/P + the rank's share of the log2 P top trees) driven
+    as the ranks of one process == the single-GPU ENTER of a full context, bit for bit; smaller HBM footprint; other calls refused"""
+    import torch
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS[field]
+    c = n // P
+    full_tree = F.build_fftree(n)
+    rng = np.random.default_rng(6)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = full_tree.enter(x)
+    full_bytes = full_tree.device_bytes
+    torch.cuda.synchronize()
+    got, L = {}, FT.lib()
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        shard = F.build_enter_shard(n, P, rank)
+        assert shard is not None and shard.n == n
+        mine = x[rank * c:(rank + 1) * c].clone()
+        got[rank] = shard.enter_sharded(comm, mine, n)
+        got[("bytes", rank)] = shard.device_bytes
+        assert L.ecfft_enter(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, None) == FT.ERR_BAD_ARG
+        assert L.ecfft_exit_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), n, None) == FT.ERR_BAD_ARG
+        assert L.ecfft_extend_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), n // 2, 1, None) == FT.ERR_BAD_ARG
+
+    _thread_ranks(P, body)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert torch.equal(got[r], want[r * c:(r + 1) * c]), (field, n, P, r)
+        if n >= 1 << 16:
+            assert got[("bytes", r)] < full_bytes

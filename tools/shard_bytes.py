@@ -18,3 +18,13 @@ for field, log_e, world in cases:
     t = time.time(); sh = F.build_extend_shard(e, world, world - 1); ts = time.time() - t
     sb = sh.device_bytes
     print(f"{field} e=2^{log_e} world={world}: full context {fb / 2**20:.1f} MiB (build {tf:.2f} s)   shard context {sb / 2**20:.1f} MiB (build {ts:.2f} s)   ratio {fb / sb:.1f}x", flush=True)
+
+for field, log_n, world in [("secp256k1", 22, 8), ("m31", 25, 8)] if len(sys.argv) <= 3 else []:
+    F = ecfft_amd.FIELDS[field]
+    n = 1 << log_n
+    t = time.time(); full = F.build_fftree(n); tf = time.time() - t
+    fb = full.device_bytes
+    del full
+    t = time.time(); sh = F.build_enter_shard(n, world, world - 1); ts = time.time() - t
+    sb = sh.device_bytes
+    print(f"{field} ENTER n=2^{log_n} world={world}: full context {fb / 2**20:.1f} MiB (build {tf:.2f} s)   ENTER-shard context {sb / 2**20:.1f} MiB (build {ts:.2f} s)   ratio {fb / sb:.1f}x", flush=True)
