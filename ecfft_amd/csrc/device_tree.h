@@ -269,6 +269,57 @@ public:
         }
         return hipGetLastError() == hipSuccess;
     }
+    // z0_s1[i] = Z_0(s1_i) (and z1_s0[i] = Z_1(s0_i)) of the tree with 2^log_m leaves WITHOUT any EXTEND: S0 is the leaf set of
+    // the subtree, and the vanishing polynomial of a leaf set factors through the isogeny chain — with A_k the image of the set in
+    // layer k (|A_k| = 2^(K-k), K = log m - 1) and psi_k = u_k / v_k, Z_{A_k}(x) = Z_{A_{k+1}}(psi_k(x)) * v_k(x)^|A_{k+1}| /
+    // lc(u_k)^|A_{k+1}|, down to the single point A_K.  The images psi_{k-1}(..psi_0(x)) of a LEAF x are the stored layers of the
+    // point set, so Z(x) = (x_K - root) * prod_k (v_k(x_k) / lc(u_k))^(2^(K-1-k)): K squarings and 2K multiplies per point.
+    // (The same holds for S1: its images are the odd-indexed points of every layer.)  which = 0: out[j] = z0_s1[i0 + j];
+    // which = 1: out[j] = z1_s0[i0 + j].  lcinv = 1 / lc(u_k), k < log N.  Used by the sharded EXIT build; build_tree keeps the
+    // reference's EXTEND-based construction (src/fftree.rs:386-397) and ecfft_selfcheck_pointwise_z compares the two.
+    void pointwise_z(unsigned log_m, int which, size_t i0, size_t cnt, E* out, const E* f, const E* lcinv, hipStream_t s) const {
+        const size_t m = (size_t)1 << log_m, stride = N_ / m, N = N_;
+        const unsigned K = log_m - 1; const E* dn = den_;
+        foreach_n(s, cnt, [=] __device__(size_t j) {
+            const size_t leaf = (2 * (i0 + j) + (which == 0 ? 1 : 0)) * stride;          // index in the top tree's layer 0
+            E U = F::one();
+            for (unsigned k = 0; k < K; ++k) {
+                const size_t lsz = N >> k;
+                const E xk = f[lsz + (leaf & (lsz - 1))];
+                const E ck = F::mul(F::mul_add(dn[2 * k + 1], xk, dn[2 * k]), lcinv[k]);
+                U = k == 0 ? ck : F::mul(F::sqr(U), ck);
+            }
+            const size_t lsz = N >> K;
+            const E xK = f[lsz + (leaf & (lsz - 1))], root = f[lsz + (which == 0 ? 0 : (stride & (lsz - 1)))];
+            out[j] = F::mul(U, F::sub(xK, root));
+        });
+    }
+    // 1 / lc(u_k) for every map of the chain, on the device (temporary)
+    E* upload_lcinv(hipStream_t s) {
+        std::vector<E> h(L_ ? L_ : 1, F::one());
+        for (unsigned k = 0; k < L_; ++k) h[k] = F::inv(host_.maps[k].num[2]);
+        E* d = temp(h.size());
+        (void)hipMemcpyAsync(d, h.data(), h.size() * sizeof(E), hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);
+        return d;
+    }
+    // test hook: number of entries of z0_s1 / z1_s0 of T_m (full context) that differ from the pointwise formula
+    long selfcheck_pointwise_z(size_t m) {
+        if (shard_mode() || m < 2 || m > N_) return -1;
+        const unsigned lm = ilog2(m); const size_t e = m / 2; hipStream_t s = nullptr;
+        E* lc = upload_lcinv(s); E* a = temp(e); E* b = temp(e);
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(temp(8));
+        (void)hipMemsetAsync(bad, 0, sizeof(unsigned long long), s);
+        pointwise_z(lm, 0, 0, e, a, f_, lc, s); pointwise_z(lm, 1, 0, e, b, f_, lc, s);
+        const E *z0 = trees_[lm].z0_s1, *z1 = trees_[lm].z1_s0;
+        foreach_n(s, e, [=] __device__(size_t i) {
+            if (!F::eq(F::canon(a[i]), F::canon(z0[i])) || !F::eq(F::canon(b[i]), F::canon(z1[i]))) atomicAdd(bad, 1ull);
+        });
+        unsigned long long h = 0;
+        bool ok = hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        temps_done();
+        return ok ? (long)h : -1;
+    }
     bool upload_points(E*& fdev, hipStream_t s) {               // the caller hipFree()s fdev
         ECFFT_HIP_TRY(hipMalloc(&fdev, 2 * N_ * sizeof(E)));
         ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));

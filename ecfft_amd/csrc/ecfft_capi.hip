@@ -639,6 +639,15 @@ size_t ecfft_tree_size(const ecfft_ctx* ctx) {
     return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->size() : ctx->m31->size();
 }
 int ecfft_field(const ecfft_ctx* ctx) { return ctx ? ctx->field : -1; }
+long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m) {
+    if (!ctx || !is_pow2(m)) return -1;
+    return guarded([&] {
+        DeviceGuard dev(ctx->device);
+        if (!dev.ok) return -1;
+        std::lock_guard<std::mutex> guard(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->lock() : ctx->m31->lock());
+        return (int)(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->selfcheck_pointwise_z(m) : ctx->m31->selfcheck_pointwise_z(m));
+    });
+}
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx) {
     if (!ctx) return 0;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->device_bytes() : ctx->m31->device_bytes();

@@ -76,6 +76,9 @@ void ecfft_ctx_destroy(ecfft_ctx* ctx);
 
 size_t ecfft_tree_size(const ecfft_ctx* ctx);   /* number of leaves of the top tree */
 int ecfft_field(const ecfft_ctx* ctx);
+/* test hook: entries of z0_s1 / z1_s0 of the subtree with m leaves (built as the reference does, src/fftree.rs:386-397) that
+ * differ from the pointwise isogeny-chain formula the sharded builds use; 0 = identical, -1 = error */
+long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m);
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch */
 
 /* coefficients -> evaluations on the leaves of T_n (n = len; any power of two <= tree size) */

@@ -100,3 +100,17 @@ def test_table_fma_building_block(trees, oracle_mod, field):
     assert np.array_equal(gt.table_fma(x, None, m, o.T_Z0_INV_S1, 3, 1, 0), F.mul(x, T))
     with pytest.raises(Exception):
         gt.table_fma(x, None, m, o.T_XNN_S, 250, 2, 0)          # index range beyond the table
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,n", [("secp256k1", 1 << 12), ("m31", 1 << 16)])
+def test_pointwise_vanishing_tables_match_the_reference_construction(field, n):
+    """z0_s1 / z1_s0 of every tree of the chain: the EXTEND-based construction of the reference (src/fftree.rs:386-397, already
+    compared with the oracle in test_tables_match_oracle) == the pointwise isogeny-chain formula used by the sharded builds"""
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    tree = ecfft_amd.FIELDS[field].build_fftree(n)
+    m = 2
+    while m <= n:
+        assert FT.lib().ecfft_selfcheck_pointwise_z(tree._h, m) == 0, (field, m)
+        m *= 2
