@@ -106,6 +106,9 @@ public:
     size_t size() const { return N_; }
     unsigned log_size() const { return L_; }
     const Tree& tree(unsigned log_m) const { return trees_[log_m]; }
+    // the table set the EXTEND machinery uses for the tree with 2^log_m leaves: trees_ / sets_, unless a temporary share of that
+    // tree is installed (the sharded EXIT build needs two different shares of one tree)
+    const Tree& tree_at(unsigned log_m) const { return (ovr_tree_ && ovr_tree_->log_m == log_m) ? *ovr_tree_ : trees_[log_m]; }
     const HostTree<F>& host() const { return host_; }
     const E* f_device() const { return f_; }
     std::mutex& lock() { return mu_; }
@@ -171,7 +174,7 @@ public:
     // HBM held by this context between calls: table arena + transform scratch (pooled temporaries of the algorithm wrappers
     // and the host-call staging buffer come and go)
     size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E); }
-    enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2 };
+    enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2, kShardExit = 3 };
     int shard_kind() const { return shard_kind_; }
     bool shard_mode() const { return shard_kind_ != kShardNone; }
     unsigned shard_log_p() const { return shard_log_p_; }
@@ -186,11 +189,12 @@ public:
     // only_target = 0 / 1: keep only what EXTENDs towards that moiety read (decompose-side tables of the source parity,
     // recombine-side tables of the target parity): half the constants; -1: both directions
     static size_t shard_set_elems(size_t c, int only_target = -1) { return (only_target < 0 ? 2 : 1) * (13 * c + 128) * kTeElems + 64; }
-    bool build_shard_set(unsigned log_m, unsigned log_p, unsigned rank, const E* f, hipStream_t s, int only_target = -1) {
+    bool build_shard_set(unsigned log_m, unsigned log_p, unsigned rank, const E* f, hipStream_t s, int only_target = -1,
+                         Tree* tout = nullptr, ShardSet* sout = nullptr) {
         const size_t m = (size_t)1 << log_m, e = m / 2, P = (size_t)1 << log_p, c = e >> log_p, stride = N_ / m;
         if (log_m < 2 || c < P || c < 2 || rank >= P) return false;
         const unsigned le = log_m - 1;
-        Tree& T = trees_[log_m]; ShardSet& S = sets_[log_m];
+        Tree& T = tout ? *tout : trees_[log_m]; ShardSet& S = sout ? *sout : sets_[log_m];
         T.m = m; T.e = e; T.log_m = log_m;
         S.valid = true; S.log_p = log_p; S.rank = rank;
         const size_t N = N_;
@@ -405,6 +409,145 @@ public:
         return true;
     }
 
+    // SHARDED EXIT context for ONE EXIT of n evaluations split over the P ranks of `tr` (api_exit_split) — a COLLECTIVE build: the
+    // full chain T_1 .. T_c (c = n/P) for the rank-local low levels, and for each top level m = c*Q the rank's share of T_m: the
+    // EXTEND tables of the split over its group of Q ranks (both directions, hc = c/2 entries per rank), its c entries of xnn_s
+    // and 1/xnn_s, its hc entries of 1/z0_s1 (pointwise_z), and its c entries of z0z0_rem_xnn_s.  The last is (Z_0^2 mod X^(m/2))
+    // on the leaves — a truncation in the monomial basis, not pointwise — and is built the way the reference builds it
+    // (src/fftree.rs:418-452) but distributed, level by level, with the very operators the split EXIT consists of:
+    //   zz0 = modular_reduce_{T_(m/2)}(z0z0' * z1z1') over the half-group (on the blocks of T_(m/2)'s tables from the level below),
+    //   zz1 = EXTEND_{T_m}(zz0 -> S1) inside the half-group (a temporary one-direction share of T_m), one exchange re-blocks
+    //   interleave(zz0, zz1) over the whole group, then two modular reductions on T_m over the group give the rank's blocks of
+    //   z0z0_rem_xnn_s and z1z1_rem_xnn_s (the latter only feeds the next level).  No tree above T_c exists on any GPU.
+    struct TempArena {           // to_tables() / take() allocate from a scratch region while this lives
+        DeviceChain* ch; E* a; size_t cap, used; E* mine = nullptr;
+        TempArena(DeviceChain* c, size_t elems) : ch(c), a(c->arena_), cap(c->arena_cap_), used(c->arena_used_) {
+            if (hipMalloc(&mine, elems * sizeof(E)) != hipSuccess) { (void)hipGetLastError(); throw DeviceAllocError(); }
+            ch->arena_ = mine; ch->arena_cap_ = elems; ch->arena_used_ = 0;
+        }
+        ~TempArena() { ch->arena_ = a; ch->arena_cap_ = cap; ch->arena_used_ = used; (void)hipFree(mine); }
+    };
+    bool build_exit_shard(HostTree<F>&& ht, int device, Transport& tr) {
+        host_ = std::move(ht);
+        N_ = host_.n; L_ = ilog2(N_); device_ = device;
+        const size_t P = (size_t)tr.world;
+        if (P < 2 || (P & (P - 1))) return false;
+        const unsigned log_p = ilog2(P), rank = (unsigned)tr.rank;
+        const size_t c = N_ >> log_p, hc = c / 2;
+        if (L_ < 2 || c < 2 * P || hc < P || rank >= P) return false;
+        const unsigned lc = ilog2(c);
+        ECFFT_HIP_TRY(hipSetDevice(device_));
+        hipStream_t s = nullptr;
+        size_t total = 64 + 3 * L_ + 4096;
+        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
+        total += log_p * (shard_set_elems(hc) + 5 * c + 256);
+        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+        arena_cap_ = total; arena_used_ = 0;
+        E* fdev = nullptr;
+        if (!upload_points(fdev, s)) return false;
+        struct Free { E* p; DeviceChain* ch; ~Free() { (void)hipFree(p); ch->f_ = nullptr; ch->ovr_tree_ = nullptr; ch->ovr_set_ = nullptr; } } free_f{fdev, this};
+        f_ = fdev;                                               // build_tree reads f_
+        if (!ensure_scratch(c)) return false;
+        trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
+        for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
+        E* lc_inv = take(L_);
+        {
+            std::vector<E> h(L_, F::one());
+            for (unsigned k = 0; k < L_; ++k) h[k] = F::inv(host_.maps[k].num[2]);
+            ECFFT_HIP_TRY(hipMemcpy(lc_inv, h.data(), L_ * sizeof(E), hipMemcpyHostToDevice));
+        }
+        shard_kind_ = kShardExit; shard_log_p_ = log_p; shard_rank_ = rank;      // extend_split must read the shares from here on
+        const E* f = fdev; const size_t N = N_;
+        bool ok = true;
+        for (size_t Q = 2; ok && Q <= P; Q *= 2) {
+            const size_t half = Q / 2, m = c * Q, stride = N_ / m;
+            const unsigned lm = ilog2(m), lq = ilog2(Q), lh = ilog2(half);
+            const int base = (int)((rank / Q) * Q), a = (int)rank - base, ap = a % (int)half, subbase = base + (a / (int)half) * (int)half;
+            const size_t blk0 = (size_t)a * c, i0 = (size_t)a * hc;
+            // ---- permanent: the rank's share of T_m for the level's split EXTENDs + its pointwise ranges
+            if (!build_shard_set(lm, lq, (unsigned)a, fdev, s, -1)) return false;
+            Tree& T = trees_[lm];
+            E *xb = take(c), *xib = take(c), *zib = take(hc), *z0b = take(c), *z1b = take(c);
+            { const uint64_t ex = m / 2; foreach_n(s, c, [=] __device__(size_t t) { xb[t] = F::pow_u64(f[N + (blk0 + t) * stride], ex); }); }
+            batch_inv(xb, xib, c, s);
+            E* zb = temp(hc);                                                      // z0_s1 on the rank's S1 range (plain), also used below
+            pointwise_z(lm, 0, i0, hc, zb, fdev, lc_inv, s);
+            batch_inv(zb, zib, hc, s);
+            T.xnn = xb - blk0; T.xnn_inv = xib - blk0; T.z0_inv_s1 = zib - i0; T.z0z0 = z0b - blk0; T.z1z1 = z1b - blk0;
+            // ---- zz0: block `ap` of modular_reduce_{T_(m/2)}(z0z0' * z1z1', c = z0z0')  (:421-425)
+            E *zz0 = temp(c), *zz1 = temp(c), *sq = temp(c);
+            E *e0 = temp(hc), *e1 = temp(hc), *h0 = temp(hc), *h1 = temp(hc), *t0 = temp(hc), *x0 = temp(hc), *x1 = temp(hc), *A = temp(c), *B = temp(c);
+            if (half == 1) {
+                const Tree& S = trees_[lc];
+                ew_mul(sq, S.z0z0, S.z1z1, c, s);
+                { const E *xi = S.xnn_inv, *x = S.xnn; foreach_n(s, hc, [=] __device__(size_t i) { e0[i] = xi[2 * i]; e1[i] = x[2 * i + 1]; }); }
+                b_modular_reduce(lc, sq, e0, e1, S.z0z0, zz0, s);
+            } else {
+                const Tree& S = trees_[lm - 1];                                   // the rank's blocks (block ap) of T_(m/2), built one level down
+                const size_t sb0 = (size_t)ap * c, si0 = (size_t)ap * hc;
+                { const E *p0 = S.z0z0 + sb0, *p1 = S.z1z1 + sb0; foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::mul(p0[2 * j], p1[2 * j]); e1[j] = F::mul(p0[2 * j + 1], p1[2 * j + 1]); }); }
+                ok = modred_split(tr, subbase, lh, m / 2, e0, e1, h0, h1, S.xnn_inv + 2 * si0, S.xnn + 2 * si0 + 1, 2, S.z0_inv_s1 + si0, S.z0z0 + 2 * si0, t0, x0, x1, A, B, s);
+                if (!ok) break;
+                foreach_n(s, hc, [=] __device__(size_t j) { zz0[2 * j] = h0[j]; zz0[2 * j + 1] = h1[j]; });
+            }
+            // ---- zz1 = EXTEND_{T_m}(zz0 -> S1) inside the half-group, c entries per rank  (:426)
+            {
+                TempArena ta(this, shard_set_elems(c, 1) + 4096);
+                Tree tt{}; ShardSet ts{};
+                if (!build_shard_set(lm, lh, (unsigned)ap, fdev, s, 1, &tt, &ts)) return false;
+                ovr_tree_ = &tt; ovr_set_ = &ts;
+                ok = half == 1 ? extend(zz0, zz1, c, 1, 1, s) : extend_split(tr, subbase, lh, zz0, zz1, m / 2, 1, s, A, B);
+                ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
+                ovr_tree_ = nullptr; ovr_set_ = nullptr;
+            }
+            if (!ok) break;
+            // ---- zz = interleave(zz0, zz1) on the rank's block [a*c, (a+1)*c) of the m leaves: the pairs [a*hc, (a+1)*hc) sit on
+            // sub-rank a/2 of either half-group  (:427-429)
+            E *pairs = temp(2 * c), *zzb = temp(c);
+            foreach_n(s, c, [=] __device__(size_t t) { pairs[2 * t] = zz0[t]; pairs[2 * t + 1] = zz1[t]; });
+            if (Q == 2) {
+                ok = hipMemcpyAsync(zzb, pairs + (size_t)a * c, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
+            } else {
+                P2P snd[2], rcv[1]; int ns = 0;
+                const int g = a / (int)half;
+                for (int r = 2 * ap; r <= 2 * ap + 1; ++r) if (r / (int)half == g) snd[ns++] = {base + r, pairs + (size_t)(r & 1) * c, c * sizeof(E)};
+                rcv[0] = {base + g * (int)half + a / 2, zzb, c * sizeof(E)};
+                ok = tr.exchange(snd, ns, rcv, 1, s);
+            }
+            if (!ok) break;
+            // ---- z0z0_rem_xnn_s on the block  (:430-446)
+            E *xqb = temp(c), *xqib = temp(c), *tmp = temp(c);
+            { const uint64_t ex = m / 4; foreach_n(s, c, [=] __device__(size_t t) { xqb[t] = F::pow_u64(f[N + (blk0 + t) * stride], ex); }); }
+            batch_inv(xqb, xqib, c, s);
+            foreach_n(s, hc, [=] __device__(size_t j) {                          // positions 2j (even: z0 = 0) and 2j+1 of the block
+                E y0 = F::neg(xb[2 * j]), y1 = F::sub(zb[j], xb[2 * j + 1]);
+                e0[j] = F::mul(F::sub(F::sqr(y0), zzb[2 * j]), xqib[2 * j]);
+                e1[j] = F::mul(F::sub(F::sqr(y1), zzb[2 * j + 1]), xqib[2 * j + 1]);
+            });
+            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xqib, xqb + 1, 2, zib, zzb, t0, x0, x1, A, B, s);
+            if (!ok) break;
+            foreach_n(s, hc, [=] __device__(size_t j) {
+                z0b[2 * j] = F::mul_add(xqb[2 * j], h0[j], zzb[2 * j]); z0b[2 * j + 1] = F::mul_add(xqb[2 * j + 1], h1[j], zzb[2 * j + 1]);
+            });
+            // ---- z1z1_rem_xnn_s on the block (:449-452): only the next level's zz0 reads it
+            E* z1s = tmp;
+            pointwise_z(lm, 1, i0, hc, z1s, fdev, lc_inv, s);
+            foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::sqr(F::sub(z1s[j], xb[2 * j])); e1[j] = F::sqr(xb[2 * j + 1]); });
+            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xib, xb + 1, 2, zib, z0b, t0, x0, x1, A, B, s);
+            if (!ok) break;
+            foreach_n(s, hc, [=] __device__(size_t j) { z1b[2 * j] = h0[j]; z1b[2 * j + 1] = h1[j]; });
+            if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
+            temps_free();
+        }
+        ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        temps_free();
+        if (!ok) { fprintf(stderr, "ecfft: sharded EXIT table build failed\n"); return false; }
+        host_.f.clear(); host_.f.shrink_to_fit();
+        ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
+        ECFFT_HIP_TRY(hipMemcpy(d_trees_, trees_.data(), (L_ + 1) * sizeof(Tree), hipMemcpyHostToDevice));
+        return true;
+    }
+
     // ------------------------------------------------------------------------------------------
     // EXTEND core: all 2*log(e) normalised stages on `total` elements = count vectors of length
     // e = m/2 laid end to end, as a chain of fused passes:
@@ -442,7 +585,7 @@ public:
                      double extra_first = 0.0, double extra_last = 0.0, unsigned k_begin = 0,
                      const NextLoad* next_ld = nullptr, bool skip_first_col = false, const EnterFuse* ef = nullptr) const {
         // k_begin > 0: only stages k >= k_begin (block-distributed shard of a split EXTEND)
-        const Tree& T = trees_[log_m];
+        const Tree& T = tree_at(log_m);
         size_t e = T.e; unsigned le = ilog2(e);
         int tgt = 1 - srcpar;
         unsigned tz = (unsigned)__builtin_ctzll((unsigned long long)total);   // tiles must divide count*e
@@ -572,7 +715,7 @@ public:
     // names the TARGET moiety.  in/out device pointers (may alias).
     bool extend(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) const {
         unsigned log_m = ilog2(e) + 1;
-        const Tree& T = trees_[log_m];
+        const Tree& T = tree_at(log_m);
         size_t total = e * count; int src = 1 - target;
         IoDesc<F> io = io_plain(in, out);
         io.ld_mode = LD_SCALE; io.ld_tbl = T.winv[src];
@@ -668,15 +811,16 @@ public:
     bool extend_split(Transport& tr, int gbase, unsigned log_p, const E* in, E* out, size_t e, int target, hipStream_t s, E* A, E* B,
                       bool cyc_in = false, bool cyc_out = false) const {
         const unsigned log_m = ilog2(e) + 1;
-        const Tree& T = trees_[log_m];
+        const Tree& T = tree_at(log_m);
         const size_t P = (size_t)1 << log_p, c = e >> log_p, cp = c >> log_p, g0 = (size_t)(tr.rank - gbase) * c;
         const unsigned r = (unsigned)(tr.rank - gbase);
         const int src = 1 - target;
         if (c < P || c < 2) return false;
         const bool sh = shard_mode();                                          // tables of this context hold only this rank's share
-        if (sh && (log_m >= sets_.size() || !sets_[log_m].valid || sets_[log_m].log_p != log_p || sets_[log_m].rank != r)) return false;
+        const ShardSet* sp = (ovr_tree_ && ovr_tree_->log_m == log_m) ? ovr_set_ : (log_m < sets_.size() && sets_[log_m].valid ? &sets_[log_m] : nullptr);
+        if (sh && (!sp || sp->log_p != log_p || sp->rank != r)) return false;
         static const ShardSet kNoSet{};
-        const ShardSet& SS = sh ? sets_[log_m] : kNoSet;
+        const ShardSet& SS = sh ? *sp : kNoSet;
         TE* const (&cyc_)[2][4] = SS.cyc; TE* const (&cycw_)[2][2] = SS.cycw;
         bool dec_done = false;
         if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
@@ -778,40 +922,41 @@ public:
         temps_done();
         return ok;
     }
+    // modular_reduce_impl (src/fftree.rs:277-281) = REDC, multiply by c, REDC (redc_impl :232-259 with moiety S0) of a length-m
+    // vector spread over the Q = 2^lq ranks [base, base + Q): every length-m/2 vector has hc = m/2Q entries per rank.  (e0, e1) =
+    // the rank's de-interleaved input, (h0, h1) = its share of the result; a0i[j*sa], a1[j*sa], zi[j] = the rank's entries of
+    // 1/a on S0, a on S1 and 1/Z_0 on S1; cc[2j], cc[2j+1] = its entries of c.  t0, x0, x1, A, B: scratch of hc elements each.
+    bool modred_split(Transport& tr, int base, unsigned lq, size_t m, const E* e0, const E* e1, E* h0, E* h1, const E* a0i, const E* a1, size_t sa,
+                      const E* zi, const E* cc, E* t0, E* x0, E* x1, E* A, E* B, hipStream_t s) {
+        const size_t e = m / 2, hc = e >> lq;
+        auto redc = [&](const E* y0, const E* y1) -> bool {
+            foreach_n(s, hc, [=] __device__(size_t j) { t0[j] = F::mul(a0i[j * sa], y0[j]); });                                    // :238
+            if (!extend_split(tr, base, lq, t0, t0, e, 1, s, A, B)) return false;                                                 // g1 (:239-245)
+            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(zi[j], F::sub(y1[j], F::mul(a1[j * sa], t0[j]))); });      // :253-255
+            return extend_split(tr, base, lq, h1, h0, e, 0, s, A, B);                                                             // :256
+        };
+        if (!redc(e0, e1)) return false;
+        foreach_n(s, hc, [=] __device__(size_t j) { x0[j] = F::mul(cc[2 * j], h0[j]); x1[j] = F::mul(cc[2 * j + 1], h1[j]); });
+        return redc(x0, x1);
+    }
     // FFTree::exit of n evaluations block-distributed over all ranks.  Level m = c*Q runs inside groups of Q ranks with every
     // length-m/2 vector spread over the whole group (c/2 entries per rank: the even / odd de-interleave is local); REDC and the
     // pointwise steps are src/fftree.rs:206-219, 232-259, 277-281 restricted to the rank's index range; one exchange per level
-    // re-blocks [u0 | v0].  Levels m <= c: the rank-local EXIT.
+    // re-blocks [u0 | v0].
     bool api_exit_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
         const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
         if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
         E* cur = temp(c); E* e0 = temp(hc); E* e1 = temp(hc); E* t0 = temp(hc); E* h0 = temp(hc); E* h1 = temp(hc); E* A = temp(hc); E* B = temp(hc);
+        E* x0 = temp(hc); E* x1 = temp(hc);
         bool ok = hipMemcpyAsync(cur, in, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
         for (size_t Q = P; ok && Q >= 2; Q /= 2) {
-            const size_t half = Q / 2, m = c * Q, e = m / 2;
+            const size_t half = Q / 2, m = c * Q;
             const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a < (int)half ? a : a - (int)half;
-            const unsigned lq = ilog2(Q);
             const Tree& T = trees_[ilog2(m)];
-            const E *xnn = T.xnn, *xi = T.xnn_inv, *zi = T.z0_inv_s1, *cc = T.z0z0;
             const size_t i0 = (size_t)a * hc;
+            const E* xi = T.xnn_inv;
             foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = cur[2 * j]; e1[j] = cur[2 * j + 1]; });
-            // redc_impl with a = xnn_s, moiety S0 (:232-259): (x0, x1) -> (h0, h1)
-            auto redc = [&](const E* x0, const E* x1) -> bool {
-                foreach_n(s, hc, [=] __device__(size_t j) { t0[j] = F::mul(xi[2 * (i0 + j)], x0[j]); });                               // :238
-                if (!extend_split(tr, base, lq, t0, t0, e, 1, s, A, B)) return false;                                                 // g1 (:239-245)
-                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(zi[i0 + j], F::sub(x1[j], F::mul(xnn[2 * (i0 + j) + 1], t0[j]))); });   // :253-255
-                return extend_split(tr, base, lq, h1, h0, e, 0, s, A, B);                                                             // :256
-            };
-            ok = redc(e0, e1);                                                                                                        // modular_reduce_impl (:277-281)
-            if (!ok) break;
-            foreach_n(s, hc, [=] __device__(size_t j) { h0[j] = F::mul(cc[2 * (i0 + j)], h0[j]); h1[j] = F::mul(cc[2 * (i0 + j) + 1], h1[j]); });
-            {   // second REDC reads (h0, h1) and overwrites them: stage its inputs
-                E* x0 = e1;                                   // e1 is free after the first REDC
-                foreach_n(s, hc, [=] __device__(size_t j) { x0[j] = h0[j]; });
-                E* x1 = cur;                                  // cur's first half is free until the re-blocking below
-                foreach_n(s, hc, [=] __device__(size_t j) { x1[j] = h1[j]; });
-                ok = redc(x0, x1);
-            }
+            ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, T.xnn_inv + 2 * i0, T.xnn + 2 * i0 + 1, 2, T.z0_inv_s1 + i0, T.z0z0 + 2 * i0, t0, x0, x1, A, B, s);
             if (!ok) break;
             // u0 = h0; v0 = (e0 - u0) * xnn_inv[even]  (:215-219), kept in h1
             foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[2 * (i0 + j)], F::sub(e0[j], h0[j])); });
@@ -1471,6 +1616,7 @@ private:
     int shard_kind_ = kShardNone;                           // sharded EXTEND-only / ENTER-only context (build_*_shard)
     unsigned shard_log_p_ = 0, shard_rank_ = 0;
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
+    const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

@@ -93,8 +93,8 @@ int guarded(Fn fn) {
 
 enum Op { OP_ENTER, OP_EXIT, OP_EXTEND };
 
-// a context made by ecfft_build_extend_shard / ecfft_build_enter_shard holds one rank's share of the tables of ONE split transform
-// and nothing else: only that transform (ecfft_extend_sharded[_layout] / ecfft_enter_sharded with the same size, world and rank;
+// a context made by ecfft_build_extend_shard / ecfft_build_enter_shard / ecfft_build_exit_shard holds one rank's share of the tables of ONE split transform
+// and nothing else: only that transform (ecfft_extend_sharded[_layout] / ecfft_enter_sharded / ecfft_exit_sharded with the same size, world and rank;
 // run_sharded checks) plus ecfft_tree_size, ecfft_field, ecfft_ctx_device_bytes, ecfft_profile_* and ecfft_ctx_destroy accept it
 inline bool shard_only(const ecfft_ctx* c) { return c->field == ECFFT_FIELD_SECP256K1 ? c->secp->shard_mode() : c->m31->shard_mode(); }
 
@@ -452,7 +452,8 @@ int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const
     if (ch.shard_mode()) {                                               // a shard context serves exactly the split it was built for
         const bool fits = P == ((size_t)1 << ch.shard_log_p()) && (unsigned)tr.rank == ch.shard_rank() &&
                           ((ch.shard_kind() == DeviceChain<F>::kShardExtend && op == OP_EXTEND && 2 * len == ch.size()) ||
-                           (ch.shard_kind() == DeviceChain<F>::kShardEnter && op == OP_ENTER && len == ch.size()));
+                           (ch.shard_kind() == DeviceChain<F>::kShardEnter && op == OP_ENTER && len == ch.size()) ||
+                           (ch.shard_kind() == DeviceChain<F>::kShardExit && op == OP_EXIT && len == ch.size()));
         if (!fits) return ECFFT_ERR_BAD_ARG;
     }
     if ((in_layout != ECFFT_LAYOUT_BLOCK && in_layout != ECFFT_LAYOUT_CYCLIC) || (out_layout != ECFFT_LAYOUT_BLOCK && out_layout != ECFFT_LAYOUT_CYCLIC)) return ECFFT_ERR_BAD_ARG;
@@ -510,12 +511,13 @@ int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
 
 namespace {
 // kind 1: EXTEND-only shard context for e = len evaluations (tree T_2e); kind 2: ENTER-only for n = len coefficients (tree T_n)
-int build_shard_ctx(int kind, int field, size_t len, int device, int world, int rank, ecfft_ctx** out) {
+int build_shard_ctx(int kind, int field, size_t len, int device, int world, int rank, ecfft_ctx** out, ecfft_comm* comm = nullptr) {
     if (!out) return ECFFT_ERR_BAD_ARG;
     *out = nullptr;
     if (!is_pow2(len) || !is_pow2((size_t)(world > 0 ? world : 0))) return ECFFT_ERR_NOT_POW2;
     if (field != ECFFT_FIELD_SECP256K1 && field != ECFFT_FIELD_M31) return ECFFT_ERR_BAD_ARG;
-    if (world > 64 || rank < 0 || rank >= world || (kind == 2 && world < 2)) return ECFFT_ERR_BAD_ARG;
+    if (world > 64 || rank < 0 || rank >= world || (kind >= 2 && world < 2)) return ECFFT_ERR_BAD_ARG;
+    if (kind == 3 && (!comm || !comm->t)) return ECFFT_ERR_BAD_ARG;
     if (len / (size_t)world < 2 * (size_t)world) return ECFFT_ERR_BAD_ARG;   // same bound as the sharded transforms
     const unsigned log_n = ilog2(len) + (kind == 1 ? 1 : 0), log_p = ilog2((size_t)world);
     if (field == ECFFT_FIELD_SECP256K1 && log_n >= 36) return ECFFT_ERR_TREE_TOO_LARGE;
@@ -531,7 +533,8 @@ int build_shard_ctx(int kind, int field, size_t len, int device, int world, int 
         DeviceGuard dev(device);
         if (!dev.ok) return (int)ECFFT_ERR_HIP;
         const bool ok = kind == 1 ? slot->build_extend_shard(std::move(ht), device, log_p, (unsigned)rank)
-                                  : slot->build_enter_shard(std::move(ht), device, log_p, (unsigned)rank);
+                      : kind == 2 ? slot->build_enter_shard(std::move(ht), device, log_p, (unsigned)rank)
+                                  : slot->build_exit_shard(std::move(ht), device, *comm->t);
         return ok ? (int)ECFFT_OK : (int)ECFFT_ERR_HIP;
     };
     int rc;
@@ -555,6 +558,10 @@ int build_shard_ctx(int kind, int field, size_t len, int device, int world, int 
 }  // namespace
 int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out) { return build_shard_ctx(1, field, e, device, world, rank, out); }
 int ecfft_build_enter_shard(int field, size_t n, int device, int world, int rank, ecfft_ctx** out) { return build_shard_ctx(2, field, n, device, world, rank, out); }
+int ecfft_build_exit_shard(int field, size_t n, int device, ecfft_comm* comm, ecfft_ctx** out) {
+    if (!comm || !comm->t) { if (out) *out = nullptr; return ECFFT_ERR_BAD_ARG; }
+    return build_shard_ctx(3, field, n, device, comm->t->world, comm->t->rank, out, comm);
+}
 
 int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_num3, const void* map_den3, int device,
                      ecfft_ctx** out) {
@@ -787,7 +794,7 @@ int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, vo
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_ENTER, coeffs, evals, n, 0, stream); });
 }
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream) {
-    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? run_sharded(ctx, *ctx->secp, comm, OP_EXIT, evals, coeffs, n, 0, stream)
                                                                     : run_sharded(ctx, *ctx->m31, comm, OP_EXIT, evals, coeffs, n, 0, stream); });
 }

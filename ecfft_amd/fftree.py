@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z", "ecfft_build_exit_shard"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -104,6 +104,7 @@ def lib():
         L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
         L.ecfft_build_enter_shard.restype, L.ecfft_build_enter_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_selfcheck_pointwise_z.restype, L.ecfft_selfcheck_pointwise_z.argtypes = ctypes.c_long, [vp, sz]
+        L.ecfft_build_exit_shard.restype, L.ecfft_build_exit_shard.argtypes = ci, [ci, sz, ci, vp, ctypes.POINTER(vp)]
         L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
         L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
@@ -166,6 +167,16 @@ class Field:
         log2(world) trees; only `enter_sharded` works on it.  None if T_n is too large for the curve."""
         h = ctypes.c_void_p()
         rc = lib().ecfft_build_enter_shard(self.id, n, device, world, rank, ctypes.byref(h))
+        if rc == ERR_TREE_TOO_LARGE:
+            return None
+        _check(rc)
+        return FFTree(self, h, device)
+
+    def build_exit_shard(self, n, comm, device=0):
+        """Sharded EXIT-only context (ecfft_build_exit_shard) — COLLECTIVE over the ranks of `comm`: the chain up to n/world plus
+        this rank's share of the top trees, z0z0_rem_xnn_s built distributed; only `exit_sharded` works on it."""
+        h = ctypes.c_void_p()
+        rc = lib().ecfft_build_exit_shard(self.id, n, device, comm._h, ctypes.byref(h))
         if rc == ERR_TREE_TOO_LARGE:
             return None
         _check(rc)

@@ -89,6 +89,14 @@ public:
         check(rc);
         return FFTree(c);
     }
+    // sharded EXIT-only context (ecfft_build_exit_shard), a COLLECTIVE build over `comm`: only exit_sharded works on it
+    static std::optional<FFTree> build_exit_shard(size_t n, const Comm& comm, int device = 0) {
+        ecfft_ctx* c = nullptr;
+        int rc = ecfft_build_exit_shard(F::id, n, device, comm.raw(), &c);
+        if (rc == ECFFT_ERR_TREE_TOO_LARGE) return std::nullopt;
+        check(rc);
+        return FFTree(c);
+    }
     // FFTree::new (src/fftree.rs:42-70): maps as 3 numerator + 3 denominator coefficients each
     static FFTree from_leaves(const std::vector<Elem>& leaves, const std::vector<Elem>& num3, const std::vector<Elem>& den3, int device = 0) {
         // the C ABI reads 3*log2(n) numerator and denominator coefficients: a short vector would be a host out-of-bounds read

@@ -158,9 +158,15 @@ int ecfft_build_extend_shard(int field, size_t e, int device, int world, int ran
  * the EXTEND tables of the split over its half-group and the c entries of xnn_s its combine step reads (src/fftree.rs:155-159).
  * All of it is pointwise in the point set: no tree above T_c is materialised on any GPU (~1/world of a full context's HBM), so
  * an ENTER can be larger than one GPU's table capacity.  Accepted by ecfft_enter_sharded only (same n, world and rank), plus
- * the informational calls listed above.  world = 2^k, 2 <= world <= 64, n / world >= 2 * world.  (A sharded EXIT context would
- * need z0_inv_s1 / z0z0_rem_xnn_s ranges of the top trees, i.e. a distributed table build: not provided.) */
+ * the informational calls listed above.  world = 2^k, 2 <= world <= 64, n / world >= 2 * world. */
 int ecfft_build_enter_shard(int field, size_t n, int device, int world, int rank, ecfft_ctx** out);
+/* Sharded EXIT-ONLY context for ONE EXIT of n evaluations over the ranks of `comm` (ecfft_exit_sharded) — a COLLECTIVE call: every
+ * rank of the communicator makes it with the same field and n.  Holds the full chain T_1 .. T_c (c = n / world) and, for each of the
+ * log2(world) top levels, only the rank's share of that tree: the EXTEND tables of the split over its group (both directions), its
+ * entries of xnn_s, 1 / xnn_s, 1 / z0_s1 (pointwise in the point set) and of z0z0_rem_xnn_s — which is built distributed, level
+ * by level, as the reference builds it (src/fftree.rs:418-452) but with the split EXIT's own operators and exchanges over `comm`.
+ * No tree above T_c is materialised on any GPU.  Accepted by ecfft_exit_sharded only (same n and communicator shape). */
+int ecfft_build_exit_shard(int field, size_t n, int device, ecfft_comm* comm, ecfft_ctx** out);
 /* ecfft_extend_sharded with a choice of distribution for the rank's shard on each side.  ECFFT_LAYOUT_CYCLIC: local element j'
  * is global position j' * world + rank.  A cyclic input saves the first of the four exchanges, a cyclic output the last one —
  * for hosts that chain split EXTENDs or that produce / consume the cyclic order anyway.  (BLOCK, BLOCK) == ecfft_extend_sharded. */

@@ -71,6 +71,13 @@ def main():
         rc = ecfft_amd.lib().ecfft_enter(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, None)      # anything else is refused
         ok = (rc == ecfft_amd.fftree.ERR_BAD_ARG) and ok
         del shard
+        # sharded ENTER-only / EXIT-only contexts (the EXIT one is a collective build over the communicator)
+        esh = F.build_enter_shard(n, world, rank)
+        ok = check("shard-context enter", esh.enter_sharded(comm, mine.clone(), n), tree.enter(full)) and ok
+        del esh
+        xsh = F.build_exit_shard(n, comm)
+        ok = check("shard-context exit", xsh.exit_sharded(comm, mine.clone(), n), tree.exit(full)) and ok
+        del xsh
         # in place (in == out is allowed by the ABI): run through the raw call
         buf = mine.clone()
         ecfft_amd.fftree._check(ecfft_amd.lib().ecfft_extend_sharded(tree._h, comm._h, buf.data_ptr(), buf.data_ptr(), n, 1,

@@ -269,3 +269,43 @@ def test_enter_shard_context_on_one_gpu(field, n, P):
         assert torch.equal(got[r], want[r * c:(r + 1) * c]), (field, n, P, r)
         if n >= 1 << 16:
             assert got[("bytes", r)] < full_bytes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8)])
+def test_exit_shard_context_on_one_gpu(field, n, P):
+    """ecfft_build_exit_shard (collective, distributed build of z0z0_rem_xnn_s): P sharded EXIT-only contexts as the ranks of one
+    process == the single-GPU EXIT of a full context on arbitrary evaluations, bit for bit; other calls refused"""
+    import torch
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS[field]
+    c = n // P
+    full_tree = F.build_fftree(n)
+    rng = np.random.default_rng(8)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = full_tree.exit(x)
+    full_bytes = full_tree.device_bytes
+    torch.cuda.synchronize()
+    got, L = {}, FT.lib()
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        shard = F.build_exit_shard(n, comm)
+        assert shard is not None and shard.n == n
+        mine = x[rank * c:(rank + 1) * c].clone()
+        got[rank] = shard.exit_sharded(comm, mine, n)
+        got[("bytes", rank)] = shard.device_bytes
+        assert L.ecfft_exit(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, None) == FT.ERR_BAD_ARG
+        assert L.ecfft_enter_sharded(shard._h, comm._h, mine.data_ptr(), mine.data_ptr(), n, None) == FT.ERR_BAD_ARG
+
+    _thread_ranks(P, body)
+    torch.cuda.synchronize()
+    for r in range(P):
+        assert torch.equal(got[r], want[r * c:(r + 1) * c]), (field, n, P, r)
+        if n >= 1 << 16:
+            assert got[("bytes", r)] < full_bytes

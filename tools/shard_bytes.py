@@ -28,3 +28,38 @@ for field, log_n, world in [("secp256k1", 22, 8), ("m31", 25, 8)] if len(sys.arg
     t = time.time(); sh = F.build_enter_shard(n, world, world - 1); ts = time.time() - t
     sb = sh.device_bytes
     print(f"{field} ENTER n=2^{log_n} world={world}: full context {fb / 2**20:.1f} MiB (build {tf:.2f} s)   ENTER-shard context {sb / 2**20:.1f} MiB (build {ts:.2f} s)   ratio {fb / sb:.1f}x", flush=True)
+
+if len(sys.argv) <= 3:
+    # EXIT-only shard contexts are a collective build: world ranks as threads of this process (exchange = barrier + D2D copies)
+    import threading
+    from ecfft_amd import distributed as D
+    from ecfft_amd import fftree as FT
+    for field, log_n, world in [("secp256k1", 22, 8), ("m31", 25, 8)]:
+        F = ecfft_amd.FIELDS[field]
+        n = 1 << log_n
+        board, bar, L, out = {}, threading.Barrier(world), FT.lib(), {}
+
+        def make_exchange(rank):
+            def exchange(user, ns, speer, sptr, sbytes, nr, rpeer, rptr, rbytes, stream):
+                L.ecfft_device_sync(0)
+                board[rank] = [(speer[i], sptr[i], sbytes[i]) for i in range(ns)]
+                bar.wait()
+                for i in range(nr):
+                    src = [q for q in board[rpeer[i]] if q[0] == rank]
+                    k = sum(1 for j in range(i) if rpeer[j] == rpeer[i])
+                    L.ecfft_device_copy(rptr[i], src[k][1], rbytes[i], 2)
+                L.ecfft_device_sync(0)
+                bar.wait()
+                return 0
+            return exchange
+
+        def run(rank):
+            comm = D.Comm.callback(world=world, rank=rank, device=0, exchange=make_exchange(rank))
+            t = time.time(); sh = F.build_exit_shard(n, comm); out[rank] = (sh.device_bytes, time.time() - t)
+            bar.wait()
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]; [t.join() for t in th]
+        full = F.build_fftree(n); fb = full.device_bytes; del full
+        sb, ts = out[world - 1]
+        print(f"{field} EXIT n=2^{log_n} world={world}: full context {fb / 2**20:.1f} MiB   EXIT-shard context {sb / 2**20:.1f} MiB per rank "
+              f"(collective build of all {world} ranks on this one GPU: {ts:.2f} s)   ratio {fb / sb:.1f}x", flush=True)
