@@ -386,15 +386,27 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     from ecfft_amd import distributed as D
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
-    tree = F.build_fftree(n, device=local_rank)
     c = n // world
     host = synth(args.field, n, 0x5EED0005)[rank * c:(rank + 1) * c]
     x = torch.from_numpy((host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).reshape(c, -1).copy()).cuda()
     comm = _make_comm(D, dist, world)
+    t_b = time.perf_counter()
+    if world > 1:
+        # sharded contexts: the chain up to n/world + this rank's share of the top trees (the EXIT one is a collective build)
+        t_enter = F.build_enter_shard(n, world, rank, device=local_rank)
+        t_exit = F.build_exit_shard(n, comm, device=local_rank)
+        tables = "sharded: chain up to n/world + the rank's share of the log2(world) top trees (ecfft_build_enter_shard / ecfft_build_exit_shard)"
+    else:
+        t_enter = t_exit = F.build_fftree(n, device=local_rank)
+        tables = "full chain (world = 1)"
+    if t_enter is None or t_exit is None:
+        raise SystemExit("n exceeds the curve's 2-adicity")
+    torch.cuda.synchronize(); build_s = time.perf_counter() - t_b
+    table_bytes = t_enter.device_bytes + (t_exit.device_bytes if t_exit is not t_enter else 0)
 
     def step():
-        ev = tree.enter_sharded(comm, x, n)
-        return tree.exit_sharded(comm, ev, n)
+        ev = t_enter.enter_sharded(comm, x, n)
+        return t_exit.exit_sharded(comm, ev, n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -430,7 +442,8 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
                           "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
                           "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT, one transform", "n": n,
-                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s): ecfft_enter_sharded / ecfft_exit_sharded; levels above n/P use split EXTENDs and one re-blocking exchange per level"},
+                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s): ecfft_enter_sharded / ecfft_exit_sharded; levels above n/P use split EXTENDs and one re-blocking exchange per level",
+                                     "tables": tables, "table_bytes_per_gpu": table_bytes, "context_build_s": build_s},
                           "phases": phases, "round_trip_ok": ok}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
