@@ -67,6 +67,25 @@ int main(int argc, char** argv) {
         check(ecfft_device_sync(device));
         shard_eq(tree->extend(x, m), m == Moiety::S1 ? "EXTEND -> S1" : "EXTEND -> S0");
     }
+    {   // the same EXTEND on a sharded EXTEND-only context: this rank's 1/world share of the tables of T_2e and nothing else
+        auto shard = FFTree<Secp256k1Fp>::build_extend_shard(e, world, rank, device);
+        if (!shard) { printf("e exceeds the curve's 2-adicity\n"); return 1; }
+        shard->extend_sharded(comm, (const Elem*)in.p, (Elem*)out.p, e, Moiety::S1, nullptr);
+        check(ecfft_device_sync(device));
+        shard_eq(tree->extend(x, Moiety::S1), "EXTEND -> S1 on a shard context");
+        printf("rank %d/%d: tables %.1f MiB (shard context) vs %.1f MiB (full context)\n", rank, world, shard->device_bytes() / 1048576.0, tree->device_bytes() / 1048576.0);
+    }
+    if (world > 1) {   // ENTER / EXIT on sharded contexts (the EXIT one is a collective build over the communicator)
+        auto esh = FFTree<Secp256k1Fp>::build_enter_shard(e, world, rank, device);
+        auto xsh = FFTree<Secp256k1Fp>::build_exit_shard(e, comm, device);
+        if (!esh || !xsh) { printf("shard context build failed\n"); return 1; }
+        esh->enter_sharded(comm, (const Elem*)in.p, (Elem*)out.p, e, nullptr);
+        check(ecfft_device_sync(device));
+        shard_eq(tree->enter(x), "ENTER on a shard context");
+        xsh->exit_sharded(comm, (const Elem*)in.p, (Elem*)out.p, e, nullptr);
+        check(ecfft_device_sync(device));
+        shard_eq(tree->exit(x), "EXIT on a shard context");
+    }
     tree->enter_sharded(comm, (const Elem*)in.p, (Elem*)out.p, e, nullptr);
     check(ecfft_device_sync(device));
     shard_eq(tree->enter(x), "ENTER");

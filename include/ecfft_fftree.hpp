@@ -147,6 +147,7 @@ public:
         check(ecfft_degree(ctx_, evals.data(), evals.size(), ECFFT_MEM_HOST, nullptr, &d));
         return d;
     }
+    size_t device_bytes() const { return ecfft_ctx_device_bytes(ctx_); }     // HBM held between calls: tables + scratch
     // device-resident variants (pointers into HBM, caller's stream)
     void enter_device(const Elem* coeffs, Elem* evals, size_t n, void* stream) const { check(ecfft_enter(ctx_, coeffs, evals, n, ECFFT_MEM_DEVICE, stream)); }
     void exit_device(const Elem* evals, Elem* coeffs, size_t n, void* stream) const { check(ecfft_exit(ctx_, evals, coeffs, n, ECFFT_MEM_DEVICE, stream)); }
