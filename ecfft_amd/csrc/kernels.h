@@ -997,6 +997,88 @@ struct LevelTables {
     E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident, one-element-per-thread stage engine for 32-byte fields in the latency regime (tiles of at most one
+// element per thread).  The pair-split sweeps above pay an LDS round trip and TWO workgroup barriers per stage for ONE
+// multiply of work; here thread `tid` keeps element `tid` of the tile in registers through every in-tile stage and fetches its
+// partner tid ^ h with eight cross-lane moves whenever h < 64 (same wave: no LDS traffic, no barrier), through LDS otherwise.
+// Roles are per lane: bit lh of tid says whether the thread produces the low or the high output of its pair — one multiply
+// each, decompose through c0t = np0*dinv as in the pair-split form, the hi role as t*d + 0 so divergent lanes share ONE
+// instruction stream.  Stages k_first .. log_e-1 of vectors of length e = 2^log_e laid end to end in a[0, len); tables are
+// the per-tree bases (entry e - 2h + i).  `a` must have been published with a barrier; ends with a barrier.
+// ---------------------------------------------------------------------------------------------
+#ifndef ECFFT_REG_ENGINE
+#define ECFFT_REG_ENGINE 1
+#endif
+template <class F>
+__device__ __forceinline__ typename F::elem lane_xor(const typename F::elem& x, uint32_t h) {
+    typename F::elem r;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) r.l[w] = (uint32_t)__shfl_xor((int)x.l[w], (int)h);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ typename F::elem lane_sel(bool c, const typename F::elem& p, const typename F::elem& q) {
+    typename F::elem r;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) r.l[w] = c ? p.l[w] : q.l[w];
+    return r;
+}
+template <class F, int BLK>
+__device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
+                                             const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
+                                             const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                             const typename F::telem* __restrict__ inner, uint32_t tid) {
+    using E = typename F::elem;
+    using TE = typename F::telem;
+    static_assert(sizeof(E) == 32, "32-byte fields");
+    const bool act = tid < len;                                             // len is a multiple of 64: wave-uniform
+    const size_t e = (size_t)1 << log_e;
+    E x = act ? a[tid] : F::zero();
+    auto partner = [&](uint32_t h) -> E {
+        if (h < 64) return act ? lane_xor<F>(x, h) : x;
+        __syncthreads();                                                    // readers of the previous LDS exchange are done
+        if (act) a[tid] = x;
+        __syncthreads();
+        return act ? a[tid ^ h] : x;
+    };
+    const uint32_t k_inner = log_e ? log_e - 1 : 0;
+    for (uint32_t k = k_first; k < k_inner; ++k) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const bool hi = (tid >> lh) & 1u;
+        const uint32_t off = (uint32_t)(e - 2 * (size_t)h) + (tid & (h - 1));
+        TE t; if (act) t = hi ? ldt(dinv, off) : ldt(c0t, off);
+        const E xp = partner(h);
+        if (act) {
+            const E A = lane_sel<F>(hi, xp, x), B = lane_sel<F>(hi, x, xp);
+            x = F::tmul_add(t, F::sub(B, A), lane_sel<F>(hi, F::zero(), A));   // lo: a + c0t*(b - a)   hi: dinv*(b - a)
+        }
+    }
+    if (log_e > 0 && k_first <= k_inner) {                                  // merged innermost stage pair (h = 1)
+        const bool hi = tid & 1u;
+        TE t; if (act) t = ldt(inner, hi ? 1u : 0u);
+        const E xp = partner(1);
+        if (act) {
+            const E A = lane_sel<F>(hi, xp, x), B = lane_sel<F>(hi, x, xp);
+            x = F::tmul_add(t, F::sub(B, A), A);
+        }
+    }
+    for (uint32_t k = k_inner; k-- > k_first;) {
+        const uint32_t lh = log_e - k - 1, h = 1u << lh;
+        const bool hi = (tid >> lh) & 1u;
+        const uint32_t off = (uint32_t)(e - 2 * (size_t)h) + (tid & (h - 1));
+        TE t; if (act) t = hi ? ldt(p1, off) : ldt(p0, off);
+        const E xp = partner(h);
+        if (act) {
+            const E A = lane_sel<F>(hi, xp, x), B = lane_sel<F>(hi, x, xp);
+            x = F::tmul_add(t, B, A);                                        // a + p*b
+        }
+    }
+    __syncthreads();
+    if (act) a[tid] = x;
+    __syncthreads();
+}
+
 // every stage (decompose then recombine) of EXTEND on `len` LDS elements = len/e vectors of length e;
 // srcpar = parity of the source moiety.  Ends with a barrier.
 template <class F, int BLK = kBlockLds>
@@ -1005,6 +1087,12 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
+    if constexpr (sizeof(E) == 32 && ECFFT_REG_ENGINE) {
+        if (len <= (uint32_t)BLK && (len & 63u) == 0) {
+            reg_extend32<F, BLK>(a, len, log_e, 0, T.c0t[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], tid);
+            return;
+        }
+    }
     if constexpr (sizeof(E) == 32) {
         if (len == BLK) {
             // PAIR-SPLIT sweeps (k_exit_low: half as many pairs as threads).  One butterfly = two multiplies; with one pair per
