@@ -137,10 +137,7 @@ public:
         ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
         // transform scratch: 5 N (grown on demand for batched calls); side stream for the two-halves schedule
         if (!ensure_scratch(N_)) return false;
-        for (nside_ = 0; nside_ < (1 << kSplitDepth) - 1 && nside_ < kMaxSides; ++nside_) {
-            if (hipStreamCreateWithFlags(&sides_[nside_], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_[nside_], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join_[nside_], hipEventDisableTiming) != hipSuccess) break;
-        }
+        create_side_streams();
         trees_.assign(L_ + 1, Tree{});
         {   // ~32 m temporaries are alive while T_m is built; one slab instead of ~80 hipMalloc/hipFree pairs per tree
             size_t want = 40 * N_ + 16384, cap_bytes = (size_t)16 << 30;
@@ -179,6 +176,13 @@ public:
     bool shard_mode() const { return shard_kind_ != kShardNone; }
     unsigned shard_log_p() const { return shard_log_p_; }
     unsigned shard_rank() const { return shard_rank_; }
+    // side streams of the two-halves schedule (enter_rec / exit_rec)
+    void create_side_streams() {
+        for (nside_ = 0; nside_ < (1 << kSplitDepth) - 1 && nside_ < kMaxSides; ++nside_) {
+            if (hipStreamCreateWithFlags(&sides_[nside_], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_[nside_], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join_[nside_], hipEventDisableTiming) != hipSuccess) break;
+        }
+    }
     // One rank's share of the EXTEND tables of the tree with 2^log_m leaves (a tree of the chain of T_N: its layer k is every
     // (N/m)-th point of the top tree's layer k) for a split over 2^log_p ranks; f = the device copy of the point set.
     struct ShardSet {
@@ -384,6 +388,7 @@ public:
         struct Free { E* p; ~Free() { (void)hipFree(p); } } free_f{fdev};
         f_ = fdev;                                               // build_tree reads f_; reset below
         if (!ensure_scratch(c)) return false;
+        create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
         trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
         for (unsigned l = 0; l <= lc; ++l) { if (!build_tree(l, s)) { f_ = nullptr; return false; } }
         for (size_t Q = 2; Q <= P; Q *= 2) {
@@ -448,6 +453,7 @@ public:
         struct Free { E* p; DeviceChain* ch; ~Free() { (void)hipFree(p); ch->f_ = nullptr; ch->ovr_tree_ = nullptr; ch->ovr_set_ = nullptr; } } free_f{fdev, this};
         f_ = fdev;                                               // build_tree reads f_
         if (!ensure_scratch(c)) return false;
+        create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
         trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
         for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
         E* lc_inv = take(L_);

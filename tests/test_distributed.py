@@ -232,7 +232,7 @@ def _thread_ranks(P, body):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16)])
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])   # last: chunk 2^20 runs the two-halves schedule
 def test_enter_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_enter_shard: P sharded ENTER-only contexts (chain up to n/P + the rank's share of the log2 P top trees) driven
     as the ranks of one process == the single-GPU ENTER of a full context, bit for bit; smaller HBM footprint; other calls refused"""
@@ -274,7 +274,7 @@ def test_enter_shard_context_on_one_gpu(field, n, P):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16)])
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])   # last: chunk 2^20 runs the two-halves schedule
 def test_exit_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_exit_shard (collective, distributed build of z0z0_rem_xnn_s): P sharded EXIT-only contexts as the ranks of one
     process == the single-GPU EXIT of a full context on arbitrary evaluations, bit for bit; other calls refused"""
