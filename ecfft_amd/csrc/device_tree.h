@@ -576,7 +576,12 @@ public:
 #ifndef ECFFT_LOG_COL_TILE_BYTES
 #define ECFFT_LOG_COL_TILE_BYTES 15
 #endif
-    static constexpr unsigned kColStages = ECFFT_COL_STAGES;      // max stages per column pass (A/B on MI355X: 8 stages x 4-element rows beat 5 x 32)
+#ifndef ECFFT_COL_STAGES_4B
+#define ECFFT_COL_STAGES_4B 9
+#endif
+    // max stages per column pass (A/B on MI355X: 8 stages x 4-element rows beat 5 x 32 on secp256k1; 9 x 16-element rows are 1 %
+    // better than 8 on M31 at 2^24 and equal below, profiles/r02/knob_sweep.txt)
+    static constexpr unsigned kColStages = sizeof(E) == 4 ? ECFFT_COL_STAGES_4B : ECFFT_COL_STAGES;
     static constexpr unsigned kLogColTileMax = (sizeof(E) == 32) ? ECFFT_LOG_COL_TILE_BYTES - 5 : ECFFT_LOG_COL_TILE_BYTES - 2;
     // Fusion of consecutive cores (EXIT): `next_ld` != nullptr says that another core of the same tree and size, opposite
     // direction, follows on `buf` with that load operator; if this core ends in a column pass, that pass and the next
