@@ -832,7 +832,7 @@ public:
         if (sh && (!sp || sp->log_p != log_p || sp->rank != r)) return false;
         static const ShardSet kNoSet{};
         const ShardSet& SS = sh ? *sp : kNoSet;
-        TE* const (&cyc_)[2][4] = SS.cyc; TE* const (&cycw_)[2][2] = SS.cycw;
+        const auto& cyc_ = SS.cyc; const auto& cycw_ = SS.cycw;               // [parity][np0, dinv, p0, p1] and [parity][w, winv], compact
         bool dec_done = false;
         if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
             dec_done = true;                                                   // 1/W + every cyclic decompose stage in one pass
@@ -866,11 +866,12 @@ public:
             extend_core(log_m, io, out, c, src, s, 0.0, 0.0, log_p);
         }
         if (!exchange_group(tr, gbase, P, B, A, cp, s)) return false;          // A = cyclic shard
+        bool rec_done = false;
         if (sh && cyclic_stages_fused(cyc_[target][2], cyc_[target][3], A, cyc_out ? out : A, c, log_p, false, nullptr, cyc_out ? cycw_[target][0] : nullptr, s)) {
             if (cyc_out) return hipGetLastError() == hipSuccess;               // every cyclic recombine stage + W in one pass
-            goto recombined;
+            rec_done = true;
         }
-        for (unsigned k = log_p; k-- > 0;) {
+        for (unsigned k = log_p; !rec_done && k-- > 0;) {
             size_t h = e >> (k + 1), off = e - 2 * h;
             if (sh) {
                 const size_t offl = c - 2 * (h >> log_p);
@@ -881,7 +882,6 @@ public:
             ECFFT_LAUNCH(KC_RECOMBINE, sizeof(E) * (2.0 * c + 4.0 * (h >> log_p)), k_recombine_stage<F>, dim3(nblocks(npairs)), dim3(kBlock), 0, s,
                          A, T.p0[target] + off, T.p1[target] + off, ilog2(h >> log_p), npairs, (uint32_t)P, r);
         }
-    recombined:
         if (cyc_out) {  // stay cyclic: W_target of positions j'*P + r
             if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, (const TE*)cycw_[target][0], c - 1, c, 1u, 0u);
             else ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, out, (const E*)A, T.w[target], c - 1, c, (uint32_t)P, r);
