@@ -368,7 +368,7 @@ public:
     // T_1 .. T_c, c = n/P, for the rank-local low levels (every rank runs the same ENTER of its chunk on T_c), and for each of
     // the log P top levels m = c*Q only the rank's share of T_m: the EXTEND tables of the split over its half-group (a ShardSet
     // with 2^log_p' = Q/2, rank' = rank mod Q/2; Q = 2 is a local EXTEND = the "split" over one rank) and the c entries of
-    // xnn_s = leaf^(m/2) its combine step reads.  All pointwise in the point set: no tree above T_c is materialised anywhere.
+    // xnn_s = leaf^(m/2) its combine step reads (the positions i'*Q + a it owns in the level's cyclic order).  All pointwise in the point set: no tree above T_c is materialised anywhere.
     // ~56 c elements for the chain + 13 c constants per top level (ENTER only extends towards S1) instead of 56 n.
     bool build_enter_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {
         host_ = std::move(ht);
@@ -392,13 +392,13 @@ public:
         trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
         for (unsigned l = 0; l <= lc; ++l) { if (!build_tree(l, s)) { f_ = nullptr; return false; } }
         for (size_t Q = 2; Q <= P; Q *= 2) {
-            const size_t half = Q / 2, m = c * Q, hc = c / 2;
+            const size_t half = Q / 2, m = c * Q;
             const unsigned lm = ilog2(m);
-            const size_t a = rank % Q, ap = a / 2, b = a % 2, i0 = ap * c + b * hc, stride = N_ / m;
+            const size_t a = rank % Q, stride = N_ / m;
             if (!build_shard_set(lm, ilog2(half), (unsigned)(a % half), fdev, s, 1)) { f_ = nullptr; return false; }   // ENTER extends towards S1 only
             E* x = take(c); const E* f = fdev; const size_t N = N_; const uint64_t ex = m / 2;
-            foreach_n(s, c, [=] __device__(size_t j) { x[j] = F::pow_u64(f[N + (2 * i0 + j) * stride], ex); });
-            trees_[lm].xnn = x - 2 * i0;
+            foreach_n(s, c, [=] __device__(size_t j) { x[j] = F::pow_u64(f[N + (j * Q + a) * stride], ex); });   // the rank's positions in the level's cyclic order
+            trees_[lm].xnn = x;
             if (hipStreamSynchronize(s) != hipSuccess) { f_ = nullptr; return false; }
             temps_free();
         }
@@ -904,32 +904,37 @@ public:
     }
     // FFTree::enter of n coefficients block-distributed over all ranks of `tr` (rank r holds [r*c, (r+1)*c), c = n/P).
     // Levels m <= c are the rank-local ENTER of the chunk; level m = c*Q (Q = 2, 4, .. P) works inside groups of Q consecutive
-    // ranks: a split EXTEND over the half-group that holds u0 (or v0), then ONE exchange re-blocks [u0 | v0 | u1 | v1] so that
-    // every rank owns the pairs whose interleaved outputs (src/fftree.rs:155-159) form its block of the level's result.
+    // ranks, and every vector of a level stays CYCLIC across it: u0 (on the lower half-group) and v0 (upper) arrive cyclic over
+    // their half-group, the split EXTEND runs cyclic-in / cyclic-out (2 exchanges; none for Q = 2), and ONE exchange hands every
+    // rank the operands of the outputs it owns in the NEXT level's cyclic order — position i = i'*Q + a of the level's result is
+    // out[i] = X + xnn_s[i] * Y (src/fftree.rs:155-159) with (X, Y) = (u0, v0)[i/2] for even i and (u1, v1)[i/2] for odd i, and
+    // all positions of a rank have the parity of a, so rank a needs the whole `cur` (a even) or `ext` (a odd) of sub-rank a/2 of
+    // both half-groups.  3 exchanges per level (block form: 5), one more at the end to return to the block order.
     bool api_enter_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
-        const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
+        const size_t P = (size_t)tr.world, c = n / P, cp = c / P;
         if ((P & (P - 1)) || c < 2 * P) return false;
-        E* cur = temp(c); E* ext = temp(c); E* R = temp(2 * c); E* A = temp(c); E* B = temp(c);
+        const bool sh = shard_mode();
+        E* cur = temp(c); E* ext = temp(c); E* U = temp(c); E* V = temp(c); E* A = temp(c); E* B = temp(c);
         bool ok = enter(in, cur, c, 1, s);
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
             const size_t half = Q / 2, m = c * Q, e = m / 2;
-            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, a2 = a % (int)half, ap = a / 2, b = a % 2;
+            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, g = a / (int)half, ap = a % (int)half;
             if (half == 1) ok = extend(cur, ext, e, 1, 1, s);
-            else ok = extend_split(tr, base + (a / (int)half) * (int)half, ilog2(half), cur, ext, e, 1, s, A, B);
+            else ok = extend_split(tr, base + g * (int)half, ilog2(half), cur, ext, e, 1, s, A, B, true, true);
             if (!ok) break;
-            P2P snd[4] = {{base + 2 * a2, cur, hc * sizeof(E)}, {base + 2 * a2, ext, hc * sizeof(E)},
-                          {base + 2 * a2 + 1, cur + hc, hc * sizeof(E)}, {base + 2 * a2 + 1, ext + hc, hc * sizeof(E)}};
-            P2P rcv[4] = {{base + ap, R, hc * sizeof(E)}, {base + ap, R + hc, hc * sizeof(E)},
-                          {base + (int)half + ap, R + 2 * hc, hc * sizeof(E)}, {base + (int)half + ap, R + 3 * hc, hc * sizeof(E)}};
-            ok = tr.exchange(snd, 4, rcv, 4, s);
-            const E* xnn = trees_[ilog2(m)].xnn; const size_t i0 = (size_t)ap * c + (size_t)b * hc;
-            const E *u0 = R, *u1 = R + hc, *v0 = R + 2 * hc, *v1 = R + 3 * hc;
-            foreach_n(s, hc, [=] __device__(size_t j) {
-                cur[2 * j] = F::mul_add(xnn[2 * (i0 + j)], v0[j], u0[j]);             // :157
-                cur[2 * j + 1] = F::mul_add(xnn[2 * (i0 + j) + 1], v1[j], u1[j]);     // :158
-            });
+            P2P snd[2] = {{base + 2 * ap, cur, c * sizeof(E)}, {base + 2 * ap + 1, ext, c * sizeof(E)}};
+            P2P rcv[2] = {{base + a / 2, U, c * sizeof(E)}, {base + (int)half + a / 2, V, c * sizeof(E)}};
+            ok = tr.exchange(snd, 2, rcv, 2, s);
+            // a shard context holds exactly the c entries xnn_s[i'*Q + a] of T_m, compact; a full one the whole table
+            const E* xnn = trees_[ilog2(m)].xnn + (sh ? 0 : a); const size_t xs = sh ? 1 : Q;
+            foreach_n(s, c, [=] __device__(size_t i) { cur[i] = F::mul_add(xnn[i * xs], V[i], U[i]); });      // :157-158
         }
-        if (ok) ok = hipMemcpyAsync(out, cur, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess && hipGetLastError() == hipSuccess;
+        if (ok) {   // cyclic over all ranks -> block: local i' = r'*cp + k is global (r'*cp + k)*P + r = block r', offset k*P + r
+            ok = exchange_group(tr, 0, P, cur, B, cp, s);
+            const size_t lp = ilog2(P);
+            foreach_n(s, c, [=] __device__(size_t i) { out[i] = B[(i & (P - 1)) * cp + (i >> lp)]; });
+        }
+        ok = ok && hipGetLastError() == hipSuccess;
         temps_done();
         return ok;
     }
