@@ -492,7 +492,8 @@ public:
                 const Tree& S = trees_[lm - 1];                                   // the rank's blocks (block ap) of T_(m/2), built one level down
                 const size_t sb0 = (size_t)ap * c, si0 = (size_t)ap * hc;
                 { const E *p0 = S.z0z0 + sb0, *p1 = S.z1z1 + sb0; foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::mul(p0[2 * j], p1[2 * j]); e1[j] = F::mul(p0[2 * j + 1], p1[2 * j + 1]); }); }
-                ok = modred_split(tr, subbase, lh, m / 2, e0, e1, h0, h1, S.xnn_inv + 2 * si0, S.xnn + 2 * si0 + 1, 2, S.z0_inv_s1 + si0, S.z0z0 + 2 * si0, t0, x0, x1, A, B, s);
+                ok = modred_split(tr, subbase, lh, m / 2, e0, e1, h0, h1, S.xnn_inv + 2 * si0, S.xnn + 2 * si0 + 1, 2, S.z0_inv_s1 + si0, 1,
+                                  S.z0z0 + 2 * si0, S.z0z0 + 2 * si0 + 1, 2, t0, x0, x1, A, B, s);
                 if (!ok) break;
                 foreach_n(s, hc, [=] __device__(size_t j) { zz0[2 * j] = h0[j]; zz0[2 * j + 1] = h1[j]; });
             }
@@ -530,7 +531,7 @@ public:
                 e0[j] = F::mul(F::sub(F::sqr(y0), zzb[2 * j]), xqib[2 * j]);
                 e1[j] = F::mul(F::sub(F::sqr(y1), zzb[2 * j + 1]), xqib[2 * j + 1]);
             });
-            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xqib, xqb + 1, 2, zib, zzb, t0, x0, x1, A, B, s);
+            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xqib, xqb + 1, 2, zib, 1, zzb, zzb + 1, 2, t0, x0, x1, A, B, s);
             if (!ok) break;
             foreach_n(s, hc, [=] __device__(size_t j) {
                 z0b[2 * j] = F::mul_add(xqb[2 * j], h0[j], zzb[2 * j]); z0b[2 * j + 1] = F::mul_add(xqb[2 * j + 1], h1[j], zzb[2 * j + 1]);
@@ -539,7 +540,7 @@ public:
             E* z1s = tmp;
             pointwise_z(lm, 1, i0, hc, z1s, fdev, lc_inv, s);
             foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::sqr(F::sub(z1s[j], xb[2 * j])); e1[j] = F::sqr(xb[2 * j + 1]); });
-            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xib, xb + 1, 2, zib, z0b, t0, x0, x1, A, B, s);
+            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xib, xb + 1, 2, zib, 1, z0b, z0b + 1, 2, t0, x0, x1, A, B, s);
             if (!ok) break;
             foreach_n(s, hc, [=] __device__(size_t j) { z1b[2 * j] = h0[j]; z1b[2 * j + 1] = h1[j]; });
             if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
@@ -939,46 +940,82 @@ public:
         return ok;
     }
     // modular_reduce_impl (src/fftree.rs:277-281) = REDC, multiply by c, REDC (redc_impl :232-259 with moiety S0) of a length-m
-    // vector spread over the Q = 2^lq ranks [base, base + Q): every length-m/2 vector has hc = m/2Q entries per rank.  (e0, e1) =
-    // the rank's de-interleaved input, (h0, h1) = its share of the result; a0i[j*sa], a1[j*sa], zi[j] = the rank's entries of
-    // 1/a on S0, a on S1 and 1/Z_0 on S1; cc[2j], cc[2j+1] = its entries of c.  t0, x0, x1, A, B: scratch of hc elements each.
+    // vector spread over the Q = 2^lq ranks [base, base + Q): every length-m/2 vector has hc = m/2Q entries per rank, in BLOCK
+    // order (entry j of the rank = position a*hc + j) or, with cyc, in CYCLIC order (position j*Q + a; the split EXTENDs then run
+    // cyclic-in / cyclic-out: 2 exchanges each instead of 4).  (e0, e1) = the rank's de-interleaved input, (h0, h1) = its share
+    // of the result; a0i[j*sa], a1[j*sa], zi[j*sz] = the rank's entries of 1/a on S0, a on S1 and 1/Z_0 on S1, cc0[j*sc], cc1[j*sc]
+    // = its entries of c on S0 / S1.  t0, x0, x1, A, B: scratch of hc elements each.
     bool modred_split(Transport& tr, int base, unsigned lq, size_t m, const E* e0, const E* e1, E* h0, E* h1, const E* a0i, const E* a1, size_t sa,
-                      const E* zi, const E* cc, E* t0, E* x0, E* x1, E* A, E* B, hipStream_t s) {
+                      const E* zi, size_t sz, const E* cc0, const E* cc1, size_t sc, E* t0, E* x0, E* x1, E* A, E* B, hipStream_t s, bool cyc = false) {
         const size_t e = m / 2, hc = e >> lq;
         auto redc = [&](const E* y0, const E* y1) -> bool {
-            foreach_n(s, hc, [=] __device__(size_t j) { t0[j] = F::mul(a0i[j * sa], y0[j]); });                                    // :238
-            if (!extend_split(tr, base, lq, t0, t0, e, 1, s, A, B)) return false;                                                 // g1 (:239-245)
-            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(zi[j], F::sub(y1[j], F::mul(a1[j * sa], t0[j]))); });      // :253-255
-            return extend_split(tr, base, lq, h1, h0, e, 0, s, A, B);                                                             // :256
+            foreach_n(s, hc, [=] __device__(size_t j) { t0[j] = F::mul(a0i[j * sa], y0[j]); });                                         // :238
+            if (!extend_split(tr, base, lq, t0, t0, e, 1, s, A, B, cyc, cyc)) return false;                                            // g1 (:239-245)
+            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(zi[j * sz], F::sub(y1[j], F::mul(a1[j * sa], t0[j]))); });      // :253-255
+            return extend_split(tr, base, lq, h1, h0, e, 0, s, A, B, cyc, cyc);                                                        // :256
         };
         if (!redc(e0, e1)) return false;
-        foreach_n(s, hc, [=] __device__(size_t j) { x0[j] = F::mul(cc[2 * j], h0[j]); x1[j] = F::mul(cc[2 * j + 1], h1[j]); });
+        foreach_n(s, hc, [=] __device__(size_t j) { x0[j] = F::mul(cc0[j * sc], h0[j]); x1[j] = F::mul(cc1[j * sc], h1[j]); });
         return redc(x0, x1);
     }
     // FFTree::exit of n evaluations block-distributed over all ranks.  Level m = c*Q runs inside groups of Q ranks with every
-    // length-m/2 vector spread over the whole group (c/2 entries per rank: the even / odd de-interleave is local); REDC and the
-    // pointwise steps are src/fftree.rs:206-219, 232-259, 277-281 restricted to the rank's index range; one exchange per level
-    // re-blocks [u0 | v0].
+    // length-m/2 vector spread over the whole group, c/2 entries per rank; REDC and the pointwise steps are
+    // src/fftree.rs:206-219, 232-259, 277-281 restricted to the rank's positions.
+    //   Full contexts keep every vector of a level CYCLIC (position j*Q + a on rank a): one all-to-all turns the user's block into
+    //   (e0, e1) cyclic over all ranks, each level is 4 cyclic split EXTENDs (8 exchanges) and ONE exchange that re-distributes
+    //   (u0 | v0) for the two half-groups of the next level — rank a's whole u0 share is exactly the even (a even) or odd (a odd)
+    //   half of what sub-rank a/2 of the lower half-group needs next, its v0 share the same for the upper half-group — 9 exchanges
+    //   per level.  Shard contexts (block ranges) run the block form: 17 per level.
     bool api_exit_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
         const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
         if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
         E* cur = temp(c); E* e0 = temp(hc); E* e1 = temp(hc); E* t0 = temp(hc); E* h0 = temp(hc); E* h1 = temp(hc); E* A = temp(hc); E* B = temp(hc);
         E* x0 = temp(hc); E* x1 = temp(hc);
-        bool ok = hipMemcpyAsync(cur, in, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
-        for (size_t Q = P; ok && Q >= 2; Q /= 2) {
-            const size_t half = Q / 2, m = c * Q;
-            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a < (int)half ? a : a - (int)half;
-            const Tree& T = trees_[ilog2(m)];
-            const size_t i0 = (size_t)a * hc;
-            const E* xi = T.xnn_inv;
-            foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = cur[2 * j]; e1[j] = cur[2 * j + 1]; });
-            ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, T.xnn_inv + 2 * i0, T.xnn + 2 * i0 + 1, 2, T.z0_inv_s1 + i0, T.z0z0 + 2 * i0, t0, x0, x1, A, B, s);
-            if (!ok) break;
-            // u0 = h0; v0 = (e0 - u0) * xnn_inv[even]  (:215-219), kept in h1
-            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[2 * (i0 + j)], F::sub(e0[j], h0[j])); });
-            P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
-            P2P rcv[2] = {{base + 2 * ap, cur, hc * sizeof(E)}, {base + 2 * ap + 1, cur + hc, hc * sizeof(E)}};
-            ok = tr.exchange(snd, 2, rcv, 2, s);
+        bool ok = true;
+        if (shard_mode()) {
+            ok = hipMemcpyAsync(cur, in, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
+            for (size_t Q = P; ok && Q >= 2; Q /= 2) {
+                const size_t half = Q / 2, m = c * Q;
+                const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a < (int)half ? a : a - (int)half;
+                const Tree& T = trees_[ilog2(m)];
+                const size_t i0 = (size_t)a * hc;
+                const E* xi = T.xnn_inv;
+                foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = cur[2 * j]; e1[j] = cur[2 * j + 1]; });
+                ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, T.xnn_inv + 2 * i0, T.xnn + 2 * i0 + 1, 2, T.z0_inv_s1 + i0, 1,
+                                  T.z0z0 + 2 * i0, T.z0z0 + 2 * i0 + 1, 2, t0, x0, x1, A, B, s);
+                if (!ok) break;
+                // u0 = h0; v0 = (e0 - u0) * xnn_inv[even]  (:215-219), kept in h1
+                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[2 * (i0 + j)], F::sub(e0[j], h0[j])); });
+                P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
+                P2P rcv[2] = {{base + 2 * ap, cur, hc * sizeof(E)}, {base + 2 * ap + 1, cur + hc, hc * sizeof(E)}};
+                ok = tr.exchange(snd, 2, rcv, 2, s);
+            }
+        } else {
+            {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
+                const size_t cpp = hc / P; const unsigned lp = ilog2(P);
+                E* S = cur;                                                      // [target r'][e0 piece | e1 piece]
+                foreach_n(s, hc, [=] __device__(size_t t) {
+                    const size_t rp = t & (P - 1), tp = t >> lp;
+                    S[rp * 2 * cpp + tp] = in[2 * t]; S[rp * 2 * cpp + cpp + tp] = in[2 * t + 1];
+                });
+                E* Rb = temp(c);
+                ok = exchange_group(tr, 0, P, S, Rb, 2 * cpp, s);
+                foreach_n(s, hc, [=] __device__(size_t j) { const size_t r = j / cpp, tp = j - r * cpp; e0[j] = Rb[r * 2 * cpp + tp]; e1[j] = Rb[r * 2 * cpp + cpp + tp]; });
+            }
+            for (size_t Q = P; ok && Q >= 2; Q /= 2) {
+                const size_t half = Q / 2, m = c * Q;
+                const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a % (int)half;
+                const Tree& T = trees_[ilog2(m)];
+                const E* xi = T.xnn_inv + 2 * a; const size_t s2 = 2 * Q;            // 1/xnn_s on the rank's S0 positions 2*(j*Q + a)
+                ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, xi, T.xnn + 2 * a + 1, s2, T.z0_inv_s1 + a, Q,
+                                  T.z0z0 + 2 * a, T.z0z0 + 2 * a + 1, s2, t0, x0, x1, A, B, s, true);
+                if (!ok) break;
+                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[j * s2], F::sub(e0[j], h0[j])); });               // :215-219
+                P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
+                P2P rcv[2] = {{base + 2 * ap, e0, hc * sizeof(E)}, {base + 2 * ap + 1, e1, hc * sizeof(E)}};
+                ok = tr.exchange(snd, 2, rcv, 2, s);
+            }
+            if (ok) foreach_n(s, hc, [=] __device__(size_t j) { cur[2 * j] = e0[j]; cur[2 * j + 1] = e1[j]; });
         }
         if (ok) ok = exit(cur, out, c, 1, s);
         ok = ok && hipGetLastError() == hipSuccess;
