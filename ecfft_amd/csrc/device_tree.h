@@ -282,14 +282,14 @@ public:
     // layer k (|A_k| = 2^(K-k), K = log m - 1) and psi_k = u_k / v_k, Z_{A_k}(x) = Z_{A_{k+1}}(psi_k(x)) * v_k(x)^|A_{k+1}| /
     // lc(u_k)^|A_{k+1}|, down to the single point A_K.  The images psi_{k-1}(..psi_0(x)) of a LEAF x are the stored layers of the
     // point set, so Z(x) = (x_K - root) * prod_k (v_k(x_k) / lc(u_k))^(2^(K-1-k)): K squarings and 2K multiplies per point.
-    // (The same holds for S1: its images are the odd-indexed points of every layer.)  which = 0: out[j] = z0_s1[i0 + j];
-    // which = 1: out[j] = z1_s0[i0 + j].  lcinv = 1 / lc(u_k), k < log N.  Used by the sharded EXIT build; build_tree keeps the
+    // (The same holds for S1: its images are the odd-indexed points of every layer.)  which = 0: out[j] = z0_s1[i0 + j*istride];
+    // which = 1: out[j] = z1_s0[i0 + j*istride].  lcinv = 1 / lc(u_k), k < log N.  Used by the sharded EXIT build; build_tree keeps the
     // reference's EXTEND-based construction (src/fftree.rs:386-397) and ecfft_selfcheck_pointwise_z compares the two.
-    void pointwise_z(unsigned log_m, int which, size_t i0, size_t cnt, E* out, const E* f, const E* lcinv, hipStream_t s) const {
+    void pointwise_z(unsigned log_m, int which, size_t i0, size_t cnt, E* out, const E* f, const E* lcinv, hipStream_t s, size_t istride = 1) const {
         const size_t m = (size_t)1 << log_m, stride = N_ / m, N = N_;
         const unsigned K = log_m - 1; const E* dn = den_;
         foreach_n(s, cnt, [=] __device__(size_t j) {
-            const size_t leaf = (2 * (i0 + j) + (which == 0 ? 1 : 0)) * stride;          // index in the top tree's layer 0
+            const size_t leaf = (2 * (i0 + j * istride) + (which == 0 ? 1 : 0)) * stride;  // index in the top tree's layer 0
             E U = F::one();
             for (unsigned k = 0; k < K; ++k) {
                 const size_t lsz = N >> k;
@@ -465,84 +465,84 @@ public:
         shard_kind_ = kShardExit; shard_log_p_ = log_p; shard_rank_ = rank;      // extend_split must read the shares from here on
         const E* f = fdev; const size_t N = N_;
         bool ok = true;
+        E *pz0[2] = {nullptr, nullptr}, *pz1[2] = {nullptr, nullptr};     // the level below: z0z0 / z1z1 _rem_xnn_s on the rank's S0 / S1 positions
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
             const size_t half = Q / 2, m = c * Q, stride = N_ / m;
             const unsigned lm = ilog2(m), lq = ilog2(Q), lh = ilog2(half);
-            const int base = (int)((rank / Q) * Q), a = (int)rank - base, ap = a % (int)half, subbase = base + (a / (int)half) * (int)half;
-            const size_t blk0 = (size_t)a * c, i0 = (size_t)a * hc;
-            // ---- permanent: the rank's share of T_m for the level's split EXTENDs + its pointwise ranges
+            const int base = (int)((rank / Q) * Q), a = (int)rank - base, g = a / (int)half, ap = a % (int)half, subbase = base + g * (int)half;
+            // Every length-m/2 vector of the level is CYCLIC over the group: entry j of the rank = position j*Q + a (api_exit_split).
+            // ---- permanent: the rank's share of T_m for the level's split EXTENDs + its pointwise entries, compact
             if (!build_shard_set(lm, lq, (unsigned)a, fdev, s, -1)) return false;
             Tree& T = trees_[lm];
-            E *xb = take(c), *xib = take(c), *zib = take(hc), *z0b = take(c), *z1b = take(c);
-            { const uint64_t ex = m / 2; foreach_n(s, c, [=] __device__(size_t t) { xb[t] = F::pow_u64(f[N + (blk0 + t) * stride], ex); }); }
-            batch_inv(xb, xib, c, s);
-            E* zb = temp(hc);                                                      // z0_s1 on the rank's S1 range (plain), also used below
-            pointwise_z(lm, 0, i0, hc, zb, fdev, lc_inv, s);
+            E *xe = temp(hc), *xei = take(hc), *xo = take(hc), *zib = take(hc), *c0 = take(hc), *c1 = take(hc), *q0 = take(hc), *q1 = take(hc);
+            { const uint64_t ex = m / 2; const size_t qq = Q, aa = (size_t)a;
+              foreach_n(s, hc, [=] __device__(size_t j) { const size_t i = j * qq + aa; xe[j] = F::pow_u64(f[N + (2 * i) * stride], ex); xo[j] = F::pow_u64(f[N + (2 * i + 1) * stride], ex); }); }
+            batch_inv(xe, xei, hc, s);
+            E* zb = temp(hc);                                                      // z0_s1 on the rank's S1 positions (plain), also used below
+            pointwise_z(lm, 0, (size_t)a, hc, zb, fdev, lc_inv, s, Q);
             batch_inv(zb, zib, hc, s);
-            T.xnn = xb - blk0; T.xnn_inv = xib - blk0; T.z0_inv_s1 = zib - i0; T.z0z0 = z0b - blk0; T.z1z1 = z1b - blk0;
-            // ---- zz0: block `ap` of modular_reduce_{T_(m/2)}(z0z0' * z1z1', c = z0z0')  (:421-425)
-            E *zz0 = temp(c), *zz1 = temp(c), *sq = temp(c);
+            // in an EXIT-shard context these fields of a top tree are the rank's COMPACT views: 1/xnn_s on its S0 positions, xnn_s on
+            // its S1 positions, 1/z0_s1, z0z0_rem_xnn_s on its S0 positions (z0z0) and on its S1 positions (z1z1 field)
+            T.xnn_inv = xei; T.xnn = xo; T.z0_inv_s1 = zib; T.z0z0 = c0; T.z1z1 = c1;
+            // ---- zz0 = modular_reduce_{T_(m/2)}(z0z0' * z1z1', c = z0z0') (:421-425), then as a length-m/2 vector cyclic over the HALF-group
+            E *Z = temp(c), *ZZ1 = temp(c);
             E *e0 = temp(hc), *e1 = temp(hc), *h0 = temp(hc), *h1 = temp(hc), *t0 = temp(hc), *x0 = temp(hc), *x1 = temp(hc), *A = temp(c), *B = temp(c);
             if (half == 1) {
                 const Tree& S = trees_[lc];
+                E* sq = temp(c);
                 ew_mul(sq, S.z0z0, S.z1z1, c, s);
                 { const E *xi = S.xnn_inv, *x = S.xnn; foreach_n(s, hc, [=] __device__(size_t i) { e0[i] = xi[2 * i]; e1[i] = x[2 * i + 1]; }); }
-                b_modular_reduce(lc, sq, e0, e1, S.z0z0, zz0, s);
+                b_modular_reduce(lc, sq, e0, e1, S.z0z0, Z, s);                      // natural order = cyclic over one rank
             } else {
-                const Tree& S = trees_[lm - 1];                                   // the rank's blocks (block ap) of T_(m/2), built one level down
-                const size_t sb0 = (size_t)ap * c, si0 = (size_t)ap * hc;
-                { const E *p0 = S.z0z0 + sb0, *p1 = S.z1z1 + sb0; foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::mul(p0[2 * j], p1[2 * j]); e1[j] = F::mul(p0[2 * j + 1], p1[2 * j + 1]); }); }
-                ok = modred_split(tr, subbase, lh, m / 2, e0, e1, h0, h1, S.xnn_inv + 2 * si0, S.xnn + 2 * si0 + 1, 2, S.z0_inv_s1 + si0, 1,
-                                  S.z0z0 + 2 * si0, S.z0z0 + 2 * si0 + 1, 2, t0, x0, x1, A, B, s);
+                const Tree& S = trees_[lm - 1];                                   // compact views of T_(m/2), built one level down (rank ap of the half-group)
+                { const E *a0 = pz0[0], *a1 = pz0[1], *b0 = pz1[0], *b1 = pz1[1]; foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::mul(a0[j], b0[j]); e1[j] = F::mul(a1[j], b1[j]); }); }
+                ok = modred_split(tr, subbase, lh, m / 2, e0, e1, h0, h1, S.xnn_inv, S.xnn, 1, S.z0_inv_s1, 1, S.z0z0, S.z1z1, 1, t0, x0, x1, A, B, s, true);
                 if (!ok) break;
-                foreach_n(s, hc, [=] __device__(size_t j) { zz0[2 * j] = h0[j]; zz0[2 * j + 1] = h1[j]; });
+                // (h0, h1)[j] = zz0 at index i = j*Q + 2*ap + {0, 1} of the length-m/2 vector; as a vector cyclic over the half-group,
+                // index i sits on sub-rank i mod half at slot i / half = 2j + t, t = (2*ap + b) / half
+                const int hq = (int)half;
+                P2P snd[2] = {{subbase + (2 * ap) % hq, h0, hc * sizeof(E)}, {subbase + (2 * ap + 1) % hq, h1, hc * sizeof(E)}};
+                const int par = ap & 1, s1 = (ap - par) / 2, s2 = s1 + hq / 2;       // the two senders whose (2*a' + par) mod half == ap
+                P2P rcv[2] = {{subbase + s1, e0, hc * sizeof(E)}, {subbase + s2, e1, hc * sizeof(E)}};
+                ok = tr.exchange(snd, 2, rcv, 2, s);
+                if (!ok) break;
+                const size_t ta = (size_t)((2 * s1 + par) / hq), tb = (size_t)((2 * s2 + par) / hq);
+                foreach_n(s, hc, [=] __device__(size_t j) { Z[2 * j + ta] = e0[j]; Z[2 * j + tb] = e1[j]; });
             }
-            // ---- zz1 = EXTEND_{T_m}(zz0 -> S1) inside the half-group, c entries per rank  (:426)
+            // ---- zz1 = EXTEND_{T_m}(zz0 -> S1) inside the half-group, c entries per rank, cyclic  (:426)
             {
                 TempArena ta(this, shard_set_elems(c, 1) + 4096);
                 Tree tt{}; ShardSet ts{};
                 if (!build_shard_set(lm, lh, (unsigned)ap, fdev, s, 1, &tt, &ts)) return false;
                 ovr_tree_ = &tt; ovr_set_ = &ts;
-                ok = half == 1 ? extend(zz0, zz1, c, 1, 1, s) : extend_split(tr, subbase, lh, zz0, zz1, m / 2, 1, s, A, B);
+                ok = half == 1 ? extend(Z, ZZ1, c, 1, 1, s) : extend_split(tr, subbase, lh, Z, ZZ1, m / 2, 1, s, A, B, true, true);
                 ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
                 ovr_tree_ = nullptr; ovr_set_ = nullptr;
             }
             if (!ok) break;
-            // ---- zz = interleave(zz0, zz1) on the rank's block [a*c, (a+1)*c) of the m leaves: the pairs [a*hc, (a+1)*hc) sit on
-            // sub-rank a/2 of either half-group  (:427-429)
-            E *pairs = temp(2 * c), *zzb = temp(c);
-            foreach_n(s, c, [=] __device__(size_t t) { pairs[2 * t] = zz0[t]; pairs[2 * t + 1] = zz1[t]; });
-            if (Q == 2) {
-                ok = hipMemcpyAsync(zzb, pairs + (size_t)a * c, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
-            } else {
-                P2P snd[2], rcv[1]; int ns = 0;
-                const int g = a / (int)half;
-                for (int r = 2 * ap; r <= 2 * ap + 1; ++r) if (r / (int)half == g) snd[ns++] = {base + r, pairs + (size_t)(r & 1) * c, c * sizeof(E)};
-                rcv[0] = {base + g * (int)half + a / 2, zzb, c * sizeof(E)};
-                ok = tr.exchange(snd, ns, rcv, 1, s);
-            }
-            if (!ok) break;
-            // ---- z0z0_rem_xnn_s on the block  (:430-446)
-            E *xqb = temp(c), *xqib = temp(c), *tmp = temp(c);
-            { const uint64_t ex = m / 4; foreach_n(s, c, [=] __device__(size_t t) { xqb[t] = F::pow_u64(f[N + (blk0 + t) * stride], ex); }); }
-            batch_inv(xqb, xqib, c, s);
-            foreach_n(s, hc, [=] __device__(size_t j) {                          // positions 2j (even: z0 = 0) and 2j+1 of the block
-                E y0 = F::neg(xb[2 * j]), y1 = F::sub(zb[j], xb[2 * j + 1]);
-                e0[j] = F::mul(F::sub(F::sqr(y0), zzb[2 * j]), xqib[2 * j]);
-                e1[j] = F::mul(F::sub(F::sqr(y1), zzb[2 * j + 1]), xqib[2 * j + 1]);
+            // ---- zz = interleave(zz0, zz1) (:427-429) on the rank's positions 2*(j*Q + a) + {0, 1}: index i = j*Q + a of zz0 / zz1 sits
+            // on this very rank (i mod half = ap) at slot i / half = 2j + g — no exchange
+            E *zc0 = temp(hc), *zc1 = temp(hc);
+            { const size_t gg = (size_t)g; foreach_n(s, hc, [=] __device__(size_t j) { zc0[j] = Z[2 * j + gg]; zc1[j] = ZZ1[2 * j + gg]; }); }
+            // ---- z0z0_rem_xnn_s on the rank's positions  (:430-446)
+            E *xqe = temp(hc), *xqo = temp(hc), *xqei = temp(hc), *xqoi = temp(hc);
+            { const uint64_t ex = m / 4; const size_t qq = Q, aa = (size_t)a;
+              foreach_n(s, hc, [=] __device__(size_t j) { const size_t i = j * qq + aa; xqe[j] = F::pow_u64(f[N + (2 * i) * stride], ex); xqo[j] = F::pow_u64(f[N + (2 * i + 1) * stride], ex); }); }
+            batch_inv(xqe, xqei, hc, s); batch_inv(xqo, xqoi, hc, s);
+            foreach_n(s, hc, [=] __device__(size_t j) {                          // even leaf: z0 = 0; odd leaf: z0 = z0_s1
+                e0[j] = F::mul(F::sub(F::sqr(xe[j]), zc0[j]), xqei[j]);
+                e1[j] = F::mul(F::sub(F::sqr(F::sub(zb[j], xo[j])), zc1[j]), xqoi[j]);
             });
-            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xqib, xqb + 1, 2, zib, 1, zzb, zzb + 1, 2, t0, x0, x1, A, B, s);
+            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xqei, xqo, 1, zib, 1, zc0, zc1, 1, t0, x0, x1, A, B, s, true);
             if (!ok) break;
-            foreach_n(s, hc, [=] __device__(size_t j) {
-                z0b[2 * j] = F::mul_add(xqb[2 * j], h0[j], zzb[2 * j]); z0b[2 * j + 1] = F::mul_add(xqb[2 * j + 1], h1[j], zzb[2 * j + 1]);
-            });
-            // ---- z1z1_rem_xnn_s on the block (:449-452): only the next level's zz0 reads it
-            E* z1s = tmp;
-            pointwise_z(lm, 1, i0, hc, z1s, fdev, lc_inv, s);
-            foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::sqr(F::sub(z1s[j], xb[2 * j])); e1[j] = F::sqr(xb[2 * j + 1]); });
-            ok = modred_split(tr, base, lq, m, e0, e1, h0, h1, xib, xb + 1, 2, zib, 1, z0b, z0b + 1, 2, t0, x0, x1, A, B, s);
+            foreach_n(s, hc, [=] __device__(size_t j) { c0[j] = F::mul_add(xqe[j], h0[j], zc0[j]); c1[j] = F::mul_add(xqo[j], h1[j], zc1[j]); });
+            // ---- z1z1_rem_xnn_s on the rank's positions (:449-452): only the next level's zz0 reads it
+            E* z1s = temp(hc);
+            pointwise_z(lm, 1, (size_t)a, hc, z1s, fdev, lc_inv, s, Q);
+            foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = F::sqr(F::sub(z1s[j], xe[j])); e1[j] = F::sqr(xo[j]); });
+            ok = modred_split(tr, base, lq, m, e0, e1, q0, q1, xei, xo, 1, zib, 1, c0, c1, 1, t0, x0, x1, A, B, s, true);
             if (!ok) break;
-            foreach_n(s, hc, [=] __device__(size_t j) { z1b[2 * j] = h0[j]; z1b[2 * j + 1] = h1[j]; });
+            pz0[0] = c0; pz0[1] = c1; pz1[0] = q0; pz1[1] = q1;
             if (hipStreamSynchronize(s) != hipSuccess) { ok = false; break; }
             temps_free();
         }
@@ -961,62 +961,46 @@ public:
     // FFTree::exit of n evaluations block-distributed over all ranks.  Level m = c*Q runs inside groups of Q ranks with every
     // length-m/2 vector spread over the whole group, c/2 entries per rank; REDC and the pointwise steps are
     // src/fftree.rs:206-219, 232-259, 277-281 restricted to the rank's positions.
-    //   Full contexts keep every vector of a level CYCLIC (position j*Q + a on rank a): one all-to-all turns the user's block into
-    //   (e0, e1) cyclic over all ranks, each level is 4 cyclic split EXTENDs (8 exchanges) and ONE exchange that re-distributes
-    //   (u0 | v0) for the two half-groups of the next level — rank a's whole u0 share is exactly the even (a even) or odd (a odd)
-    //   half of what sub-rank a/2 of the lower half-group needs next, its v0 share the same for the upper half-group — 9 exchanges
-    //   per level.  Shard contexts (block ranges) run the block form: 17 per level.
+    //   Every vector of a level stays CYCLIC (position j*Q + a on rank a): one all-to-all turns the user's block into (e0, e1)
+    //   cyclic over all ranks, each level is 4 cyclic split EXTENDs (8 exchanges) and ONE exchange that re-distributes (u0 | v0)
+    //   for the two half-groups of the next level — rank a's whole u0 share is exactly the even (a even) or odd (a odd) half of
+    //   what sub-rank a/2 of the lower half-group needs next, its v0 share the same for the upper half-group: 9 exchanges per
+    //   level (block form: 17).
     bool api_exit_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
         const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
         if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
         E* cur = temp(c); E* e0 = temp(hc); E* e1 = temp(hc); E* t0 = temp(hc); E* h0 = temp(hc); E* h1 = temp(hc); E* A = temp(hc); E* B = temp(hc);
         E* x0 = temp(hc); E* x1 = temp(hc);
         bool ok = true;
-        if (shard_mode()) {
-            ok = hipMemcpyAsync(cur, in, c * sizeof(E), hipMemcpyDeviceToDevice, s) == hipSuccess;
-            for (size_t Q = P; ok && Q >= 2; Q /= 2) {
-                const size_t half = Q / 2, m = c * Q;
-                const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a < (int)half ? a : a - (int)half;
-                const Tree& T = trees_[ilog2(m)];
-                const size_t i0 = (size_t)a * hc;
-                const E* xi = T.xnn_inv;
-                foreach_n(s, hc, [=] __device__(size_t j) { e0[j] = cur[2 * j]; e1[j] = cur[2 * j + 1]; });
-                ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, T.xnn_inv + 2 * i0, T.xnn + 2 * i0 + 1, 2, T.z0_inv_s1 + i0, 1,
-                                  T.z0z0 + 2 * i0, T.z0z0 + 2 * i0 + 1, 2, t0, x0, x1, A, B, s);
-                if (!ok) break;
-                // u0 = h0; v0 = (e0 - u0) * xnn_inv[even]  (:215-219), kept in h1
-                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[2 * (i0 + j)], F::sub(e0[j], h0[j])); });
-                P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
-                P2P rcv[2] = {{base + 2 * ap, cur, hc * sizeof(E)}, {base + 2 * ap + 1, cur + hc, hc * sizeof(E)}};
-                ok = tr.exchange(snd, 2, rcv, 2, s);
-            }
-        } else {
-            {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
-                const size_t cpp = hc / P; const unsigned lp = ilog2(P);
-                E* S = cur;                                                      // [target r'][e0 piece | e1 piece]
-                foreach_n(s, hc, [=] __device__(size_t t) {
-                    const size_t rp = t & (P - 1), tp = t >> lp;
-                    S[rp * 2 * cpp + tp] = in[2 * t]; S[rp * 2 * cpp + cpp + tp] = in[2 * t + 1];
-                });
-                E* Rb = temp(c);
-                ok = exchange_group(tr, 0, P, S, Rb, 2 * cpp, s);
-                foreach_n(s, hc, [=] __device__(size_t j) { const size_t r = j / cpp, tp = j - r * cpp; e0[j] = Rb[r * 2 * cpp + tp]; e1[j] = Rb[r * 2 * cpp + cpp + tp]; });
-            }
-            for (size_t Q = P; ok && Q >= 2; Q /= 2) {
-                const size_t half = Q / 2, m = c * Q;
-                const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a % (int)half;
-                const Tree& T = trees_[ilog2(m)];
-                const E* xi = T.xnn_inv + 2 * a; const size_t s2 = 2 * Q;            // 1/xnn_s on the rank's S0 positions 2*(j*Q + a)
-                ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, xi, T.xnn + 2 * a + 1, s2, T.z0_inv_s1 + a, Q,
-                                  T.z0z0 + 2 * a, T.z0z0 + 2 * a + 1, s2, t0, x0, x1, A, B, s, true);
-                if (!ok) break;
-                foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[j * s2], F::sub(e0[j], h0[j])); });               // :215-219
-                P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
-                P2P rcv[2] = {{base + 2 * ap, e0, hc * sizeof(E)}, {base + 2 * ap + 1, e1, hc * sizeof(E)}};
-                ok = tr.exchange(snd, 2, rcv, 2, s);
-            }
-            if (ok) foreach_n(s, hc, [=] __device__(size_t j) { cur[2 * j] = e0[j]; cur[2 * j + 1] = e1[j]; });
+        const bool sh = shard_mode();
+        {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
+            const size_t cpp = hc / P; const unsigned lp = ilog2(P);
+            E* S = cur;                                                      // [target r'][e0 piece | e1 piece]
+            foreach_n(s, hc, [=] __device__(size_t t) {
+                const size_t rp = t & (P - 1), tp = t >> lp;
+                S[rp * 2 * cpp + tp] = in[2 * t]; S[rp * 2 * cpp + cpp + tp] = in[2 * t + 1];
+            });
+            E* Rb = temp(c);
+            ok = exchange_group(tr, 0, P, S, Rb, 2 * cpp, s);
+            foreach_n(s, hc, [=] __device__(size_t j) { const size_t r = j / cpp, tp = j - r * cpp; e0[j] = Rb[r * 2 * cpp + tp]; e1[j] = Rb[r * 2 * cpp + cpp + tp]; });
         }
+        for (size_t Q = P; ok && Q >= 2; Q /= 2) {
+            const size_t half = Q / 2, m = c * Q;
+            const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a % (int)half;
+            const Tree& T = trees_[ilog2(m)];
+            // the rank's entries of 1/xnn_s on S0, xnn_s on S1, 1/z0_s1 and z0z0_rem_xnn_s on S0 / S1 (positions j*Q + a of each
+            // half): strided views of the full tables, or the compact arrays an EXIT-shard context holds in the same fields
+            const size_t s2 = sh ? 1 : 2 * Q, s1 = sh ? 1 : Q;
+            const E *xi = sh ? T.xnn_inv : T.xnn_inv + 2 * a, *xo = sh ? T.xnn : T.xnn + 2 * a + 1, *zi = sh ? T.z0_inv_s1 : T.z0_inv_s1 + a;
+            const E *cc0 = sh ? T.z0z0 : T.z0z0 + 2 * a, *cc1 = sh ? T.z1z1 : T.z0z0 + 2 * a + 1;
+            ok = modred_split(tr, base, ilog2(Q), m, e0, e1, h0, h1, xi, xo, s2, zi, s1, cc0, cc1, s2, t0, x0, x1, A, B, s, true);
+            if (!ok) break;
+            foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[j * s2], F::sub(e0[j], h0[j])); });               // :215-219
+            P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
+            P2P rcv[2] = {{base + 2 * ap, e0, hc * sizeof(E)}, {base + 2 * ap + 1, e1, hc * sizeof(E)}};
+            ok = tr.exchange(snd, 2, rcv, 2, s);
+        }
+        if (ok) foreach_n(s, hc, [=] __device__(size_t j) { cur[2 * j] = e0[j]; cur[2 * j + 1] = e1[j]; });
         if (ok) ok = exit(cur, out, c, 1, s);
         ok = ok && hipGetLastError() == hipSuccess;
         temps_done();

@@ -128,7 +128,9 @@ int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, un
  *       the other ranks by any means (MPI, TCP, a file, torch.distributed); every context of the job is built for its own GPU.
  *   ecfft_comm_init_callback   the host moves the device buffers itself (tests: several ranks sharing one GPU over gloo).
  * Arguments: device pointers only; `in` / `out` = this rank's BLOCK shard (len / world elements, may alias); world = 2^k;
- * len / world >= 2 * world.  Every rank of the communicator makes the same call with the same len.  Asynchronous on `stream`. */
+ * len / world >= 2 * world.  Every rank of the communicator makes the same call with the same len.  Asynchronous on `stream`.
+ * Exchanges (grouped send / receive calls) per transform: EXTEND 4 (2 per cyclic side saved, ecfft_extend_sharded_layout); ENTER
+ * 3 per top level + 1 (Q = 2: 1); EXIT 1 + 9 per top level — inside a level every vector stays cyclic over its group. */
 typedef struct ecfft_comm ecfft_comm;
 #define ECFFT_COMM_ID_BYTES 128
 /* n sends and n receives of device buffers that must progress together; return 0 on success */
