@@ -215,10 +215,11 @@ def cyclic_to_block(y, world, group=None):
     return recv.reshape(world, c // world, -1).transpose(0, 1).contiguous().reshape(c, -1)
 
 
-def extend_sharded(ops, x_block, e, moiety, group=None):
+def extend_sharded(ops, x_block, e, moiety, group=None, cyclic_in=False, cyclic_out=False):
     """FFTree::extend (src/fftree.rs:123-126) of ONE length-e vector held block-distributed over the
     process group.  x_block: this rank's e/P elements as a [e/P, limbs] (or [e/P]) tensor.  Returns the
-    rank's block shard of the result."""
+    rank's block shard of the result.  cyclic_in / cyclic_out: the shard on that side is the cyclic one (local j' = global
+    j'*P + rank) and that side's all-to-all disappears (ecfft_extend_sharded_layout)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     assert world & (world - 1) == 0, "power-of-two number of ranks"
@@ -227,13 +228,13 @@ def extend_sharded(ops, x_block, e, moiety, group=None):
     c = shape[0]
     assert c * world == e and c >= 2 * world, "need e/P elements per rank and at least 2P of them"
     x = x_block.reshape(c, -1)
-    y = block_to_cyclic(x, world, group)                  # world == 1: a self all-to-all, log_p = 0 (no cyclic stage)
+    y = x.clone() if cyclic_in else block_to_cyclic(x, world, group)   # world == 1: a self all-to-all, log_p = 0 (no cyclic stage)
     ops.top_cyclic(y, e, moiety, log_p, rank, False)
     z = cyclic_to_block(y, world, group)
     ops.local_block(z, e, moiety, log_p)
     y = block_to_cyclic(z, world, group)
     ops.top_cyclic(y, e, moiety, log_p, rank, True)
-    out = cyclic_to_block(y, world, group)
+    out = y if cyclic_out else cyclic_to_block(y, world, group)
     return out.reshape(shape)
 
 
@@ -241,9 +242,11 @@ def extend_sharded(ops, x_block, e, moiety, group=None):
 # ONE ENTER / EXIT of n coefficients split over the P ranks.
 # Block distribution: rank r holds positions [r*c, (r+1)*c), c = n/P, of the coefficient / evaluation vector.
 #   * levels with block size m <= c touch one rank only: they are the local ENTER / EXIT of the rank's chunk;
-#   * level m = c*2^j (j = 1..log2 P) works inside groups of Q = 2^j consecutive ranks: its EXTENDs are split-EXTENDs over
-#     (half-)groups, its pointwise steps are `table_fma` calls on index ranges, and one all_to_all_single with split sizes
-#     per level re-blocks the result (ENTER: interleave of S0/S1 halves; EXIT: [u0 | v0] concatenation).
+#   * level m = c*2^j (j = 1..log2 P) works inside groups of Q = 2^j consecutive ranks with every vector CYCLIC over the
+#     (half-)group (entry j of rank a = position j*Q + a): its EXTENDs are cyclic-in / cyclic-out split-EXTENDs, its pointwise
+#     steps are `table_fma` calls at those strided positions, and one all_to_all_single with split sizes per level moves the
+#     data to the next level's order; one more all-to-all at the user's block boundary.  The C++ path (device_tree.h
+#     api_enter_split / api_exit_split) is this algorithm; the CPU tests run it on the oracle's local operators.
 # ------------------------------------------------------------------------------------------------------------------
 def make_groups():
     """every group of 2^j consecutive ranks, j >= 1 (collective: all ranks call it once, in the same order)"""
@@ -259,10 +262,10 @@ def make_groups():
     return groups
 
 
-def _extend(ops, x, e, moiety, group):
+def _extend(ops, x, e, moiety, group, cyclic=False):
     if group is None or dist.get_world_size(group) == 1:
-        return ops.extend_local(x, moiety)
-    return extend_sharded(ops, x, e, moiety, group)
+        return ops.extend_local(x, moiety)                     # one rank: cyclic order == natural order
+    return extend_sharded(ops, x, e, moiety, group, cyclic_in=cyclic, cyclic_out=cyclic)
 
 
 def _a2a_split(pieces, dests, srcs, piece_len, Q, like, group):
@@ -281,7 +284,10 @@ def _a2a_split(pieces, dests, srcs, piece_len, Q, like, group):
 
 def enter_sharded(ops, x_block, n, groups):
     """FFTree::enter (src/fftree.rs:164-167) of n coefficients held block-distributed; returns this rank's block of
-    the evaluations (leaf order)."""
+    the evaluations (leaf order).  The MODEL of DeviceChain::api_enter_split: every vector of a top level stays CYCLIC over
+    its (half-)group — position i = i'*Q + a of the level's result on rank a — so the split EXTEND runs cyclic-in / cyclic-out
+    and one exchange per level hands rank a the whole `cur` (a even: its outputs are the even positions, u0 + xnn*v0) or `ext`
+    (a odd: u1 + xnn*v1) share of sub-rank a/2 of both half-groups."""
     world, rank = dist.get_world_size(), dist.get_rank()
     c = x_block.shape[0]
     assert c * world == n
@@ -294,31 +300,34 @@ def enter_sharded(ops, x_block, n, groups):
         base = (rank // Q) * Q
         a = rank - base
         m, e = c * Q, c * Q // 2
-        ext = _extend(ops, cur, e, S1, groups.get(half) if half > 1 else None)       # u1 (first half-group) or v1 (second)
-        a2 = a % half                                                                 # which chunk of u / v this rank holds
-        hc = c // 2
-        pieces = [torch.cat([cur[h * hc:(h + 1) * hc].reshape(-1), ext[h * hc:(h + 1) * hc].reshape(-1)]) for h in (0, 1)]
-        ap, b = a // 2, a % 2
-        got = _a2a_split(pieces, [2 * a2, 2 * a2 + 1], [ap, half + ap], 2 * hc * limbs, Q, cur, groups[Q])
-        u0h, u1h = got[0][:hc * limbs].reshape(hc, limbs), got[0][hc * limbs:].reshape(hc, limbs)
-        v0h, v1h = got[1][:hc * limbs].reshape(hc, limbs), got[1][hc * limbs:].reshape(hc, limbs)
-        i0 = ap * c + b * hc                                                          # first pair index of this rank's output
-        even = ops.table_fma(v0h.contiguous(), u0h.contiguous(), m, TBL_XNN_S, 2 * i0, 2, 1)        # u0 + x[2i]   * v0  (:157)
-        odd = ops.table_fma(v1h.contiguous(), u1h.contiguous(), m, TBL_XNN_S, 2 * i0 + 1, 2, 1)     # u1 + x[2i+1] * v1  (:158)
-        cur = torch.stack([even.reshape(hc, limbs), odd.reshape(hc, limbs)], dim=1).reshape(c, limbs).contiguous()
+        ext = _extend(ops, cur, e, S1, groups.get(half) if half > 1 else None, cyclic=True)   # u1 (lower half-group) or v1 (upper)
+        ap = a % half
+        got = _a2a_split([cur.reshape(-1), ext.reshape(-1)], [2 * ap, 2 * ap + 1], [a // 2, half + a // 2], c * limbs, Q, cur, groups[Q])
+        U, V = got[0].reshape(c, limbs), got[1].reshape(c, limbs)
+        cur = ops.table_fma(V.contiguous(), U.contiguous(), m, TBL_XNN_S, a, Q, 1).reshape(c, limbs)   # out[i'*Q + a] = U + xnn_s * V  (:157-158)
         Q *= 2
-    return cur.reshape(shape)
+    out = cyclic_to_block(cur, world) if world > 1 else cur                                    # cyclic over all ranks -> the user's block
+    return out.reshape(shape)
 
 
 def exit_sharded(ops, y_block, n, groups):
     """FFTree::exit (src/fftree.rs:227-230) of n evaluations held block-distributed; returns this rank's block of the
-    coefficients."""
+    coefficients.  The MODEL of DeviceChain::api_exit_split: one all-to-all turns the block into (e0, e1) cyclic over all
+    ranks; inside a level every length-m/2 vector is cyclic over the group of Q ranks (entry j = position j*Q + a), the
+    tables are read at those positions, the four EXTENDs run cyclic-in / cyclic-out, and one exchange re-distributes
+    (u0 | v0): rank a's whole u0 share is the even (a even) or odd (a odd) half of what sub-rank a/2 of the lower half-group
+    needs next, its v0 share the same for the upper half-group."""
     world, rank = dist.get_world_size(), dist.get_rank()
     c = y_block.shape[0]
     assert c * world == n
     shape = y_block.shape
     cur = y_block.reshape(c, -1).contiguous()
     limbs = cur.shape[1]
+    hc = c // 2
+    pairs = cur.reshape(hc, 2 * limbs)                         # row t = (even, odd) entry of pair t of the chunk
+    if world > 1:
+        pairs = block_to_cyclic(pairs, world)                 # row j' = pair j'*P + rank of the whole vector
+    e0, e1 = pairs[:, :limbs].contiguous(), pairs[:, limbs:].contiguous()
     Q = world
     while Q >= 2:
         half = Q // 2
@@ -326,25 +335,22 @@ def exit_sharded(ops, y_block, n, groups):
         a = rank - base
         m, e = c * Q, c * Q // 2
         G = groups[Q]
-        hc = c // 2
-        i0 = a * hc                                            # this rank holds pairs i0 .. i0 + c/2 of its block
-        e0, e1 = cur[0::2].contiguous(), cur[1::2].contiguous()
 
-        def redc(x0, x1):                                      # redc_impl with a = xnn_s, moiety S0 (:232-259)
-            t0 = ops.table_fma(x0, None, m, TBL_XNN_S_INV, 2 * i0, 2, 0)
-            g1 = _extend(ops, t0, e, S1, G)
-            h1 = ops.table_fma(ops.table_fma(g1, x1, m, TBL_XNN_S, 2 * i0 + 1, 2, 2), None, m, TBL_Z0_INV_S1, i0, 1, 0)
-            h0 = _extend(ops, h1, e, S0, G)
+        def redc(x0, x1):                                      # redc_impl with a = xnn_s, moiety S0 (:232-259), at positions j*Q + a
+            t0 = ops.table_fma(x0, None, m, TBL_XNN_S_INV, 2 * a, 2 * Q, 0)
+            g1 = _extend(ops, t0, e, S1, G, cyclic=True)
+            h1 = ops.table_fma(ops.table_fma(g1, x1, m, TBL_XNN_S, 2 * a + 1, 2 * Q, 2), None, m, TBL_Z0_INV_S1, a, Q, 0)
+            h0 = _extend(ops, h1, e, S0, G, cyclic=True)
             return h0, h1
         h0, h1 = redc(e0, e1)                                  # modular_reduce_impl (:277-281)
-        hc0 = ops.table_fma(h0, None, m, TBL_Z0Z0, 2 * i0, 2, 0)
-        hc1 = ops.table_fma(h1, None, m, TBL_Z0Z0, 2 * i0 + 1, 2, 0)
+        hc0 = ops.table_fma(h0, None, m, TBL_Z0Z0, 2 * a, 2 * Q, 0)
+        hc1 = ops.table_fma(h1, None, m, TBL_Z0Z0, 2 * a + 1, 2 * Q, 0)
         u0, _ = redc(hc0, hc1)
-        v0 = ops.table_fma(u0, e0, m, TBL_XNN_S_INV, 2 * i0, 2, 3)                    # (e0 - u0) * xinv  (:217-219)
-        # block <- [u0 | v0]: u0 part to group rank a//2, v0 part to group rank Q/2 + a//2
-        ap = a if a < half else a - half
+        v0 = ops.table_fma(u0, e0, m, TBL_XNN_S_INV, 2 * a, 2 * Q, 3)                 # (e0 - u0) * xinv  (:217-219)
+        ap = a % half
         got = _a2a_split([u0.reshape(-1), v0.reshape(-1)], [a // 2, half + a // 2], [2 * ap, 2 * ap + 1], hc * limbs, Q, cur, G)
-        cur = torch.cat([got[0].reshape(hc, limbs), got[1].reshape(hc, limbs)]).contiguous()
+        e0, e1 = got[0].reshape(hc, limbs).contiguous(), got[1].reshape(hc, limbs).contiguous()
         Q //= 2
+    cur = torch.stack([e0, e1], dim=1).reshape(c, limbs).contiguous()
     out = ops.exit_local(cur)
     return out.reshape(shape)
