@@ -39,6 +39,25 @@ def test_elem_sizes_and_limits_without_gpu(prod):
         prod.secp256k1.build_fftree(48)
 
 
+def test_shard_context_argument_errors_without_gpu(prod):
+    """ecfft_build_extend_shard / _enter_shard / _exit_shard reject bad shapes before touching a device"""
+    import ctypes as C
+    L, F = prod.lib(), prod.fftree
+    h = C.c_void_p()
+    for fn in (L.ecfft_build_extend_shard, L.ecfft_build_enter_shard):
+        assert fn(0, 48, 0, 2, 0, C.byref(h)) == F.ERR_NOT_POW2 and not h.value            # length
+        assert fn(0, 1 << 12, 0, 3, 0, C.byref(h)) == F.ERR_NOT_POW2                       # world
+        assert fn(0, 1 << 12, 0, 4, 4, C.byref(h)) == F.ERR_BAD_ARG                        # rank out of range
+        assert fn(0, 1 << 12, 0, 128, 0, C.byref(h)) == F.ERR_BAD_ARG                      # more than 64 ranks
+        assert fn(0, 16, 0, 4, 0, C.byref(h)) == F.ERR_BAD_ARG                             # fewer than 2*world elements per rank
+        assert fn(7, 1 << 12, 0, 2, 0, C.byref(h)) == F.ERR_BAD_ARG                        # unknown field
+        assert fn(0, 1 << 12, 0, 2, 0, None) == F.ERR_BAD_ARG
+    assert L.ecfft_build_enter_shard(0, 1 << 12, 0, 1, 0, C.byref(h)) == F.ERR_BAD_ARG     # an ENTER over one rank is ecfft_enter
+    assert L.ecfft_build_extend_shard(0, 1 << 35, 0, 2, 0, C.byref(h)) == F.ERR_TREE_TOO_LARGE   # T_2e beyond the curve's 2-adicity
+    assert L.ecfft_build_enter_shard(1, 1 << 29, 0, 2, 0, C.byref(h)) == F.ERR_TREE_TOO_LARGE
+    assert L.ecfft_build_exit_shard(0, 1 << 12, 0, None, C.byref(h)) == F.ERR_BAD_ARG      # no communicator
+
+
 def test_no_cpu_fallback(prod):
     import torch
     if torch.cuda.is_available():
