@@ -28,15 +28,23 @@ def synth(field, n, seed):
 
 
 def main():
-    dist.init_process_group("gloo")
+    # ECFFT_WORKER_RCCL=1 (multi-GPU hosts): one rank per GPU, exchanges over the real RCCL transport (grouped ncclSend / ncclRecv)
+    rccl = os.environ.get("ECFFT_WORKER_RCCL") == "1"
+    if rccl:
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dev = 0
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
     ok = True
-    comm = D.Comm.callback()
+    comm = D.Comm.rccl(device=dev) if rccl else D.Comm.callback()
     assert comm.rank == rank and comm.world == world
     for field, n in (("secp256k1", 1 << 13), ("m31", 1 << 16)):
         F = ecfft_amd.FIELDS[field]
-        tree = F.build_fftree(2 * n)
+        tree = F.build_fftree(2 * n, device=dev)
         x = synth(field, n, 11)                                            # same on every rank
         view = np.int64 if field == "secp256k1" else np.int32
         c = n // world
@@ -65,19 +73,20 @@ def main():
             if not torch.equal(got, want[rank::world]):
                 print(f"rank {rank}: {field} extend cyclic-in-out {moiety} MISMATCH", flush=True); ok = False
         # sharded EXTEND-only context: this rank's share of the tables only (ecfft_build_extend_shard), same results
-        shard = F.build_extend_shard(n, world, rank)
+        shard = F.build_extend_shard(n, world, rank, device=dev)
         for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
             ok = check(f"shard-context extend {moiety}", shard.extend_sharded(comm, mine.clone(), n, moiety), tree.extend(full, moiety)) and ok
         rc = ecfft_amd.lib().ecfft_enter(shard._h, mine.data_ptr(), mine.data_ptr(), c, 1, None)      # anything else is refused
         ok = (rc == ecfft_amd.fftree.ERR_BAD_ARG) and ok
         del shard
         # sharded ENTER-only / EXIT-only contexts (the EXIT one is a collective build over the communicator)
-        esh = F.build_enter_shard(n, world, rank)
-        ok = check("shard-context enter", esh.enter_sharded(comm, mine.clone(), n), tree.enter(full)) and ok
-        del esh
-        xsh = F.build_exit_shard(n, comm)
-        ok = check("shard-context exit", xsh.exit_sharded(comm, mine.clone(), n), tree.exit(full)) and ok
-        del xsh
+        if world > 1:
+            esh = F.build_enter_shard(n, world, rank, device=dev)
+            ok = check("shard-context enter", esh.enter_sharded(comm, mine.clone(), n), tree.enter(full)) and ok
+            del esh
+            xsh = F.build_exit_shard(n, comm, device=dev)
+            ok = check("shard-context exit", xsh.exit_sharded(comm, mine.clone(), n), tree.exit(full)) and ok
+            del xsh
         # in place (in == out is allowed by the ABI): run through the raw call
         buf = mine.clone()
         ecfft_amd.fftree._check(ecfft_amd.lib().ecfft_extend_sharded(tree._h, comm._h, buf.data_ptr(), buf.data_ptr(), n, 1,
@@ -89,7 +98,7 @@ def main():
         torch.cuda.synchronize()
     st = comm.stats()
     ok = ok and st["exchanges"] > 0
-    flag = torch.tensor([1 if ok else 0])
+    flag = torch.tensor([1 if ok else 0], device="cuda" if rccl else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("DIST_GPU_OK" if int(flag.item()) == 1 else "DIST_GPU_FAIL")

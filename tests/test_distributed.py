@@ -39,6 +39,33 @@ def test_sharded_transforms_with_hip_ops(world):
 
 
 @pytest.mark.gpu
+def test_sharded_transforms_over_rccl_multi_gpu():
+    """the same worker with ONE RANK PER GPU over the real RCCL transport (grouped ncclSend / ncclRecv over xGMI): full and sharded
+    contexts, block and cyclic layouts, against the single-GPU transforms.  Needs >= 2 GPUs (skipped on the one-GPU lease)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("one GPU: RCCL refuses several ranks on one device (covered with world = 1 below and with gloo above)")
+    world = 1 << (min(ndev, 8).bit_length() - 1)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ECFFT_WORKER_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_worker_with_one_rank():
+    """the multi-GPU worker in its RCCL mode (nccl process group, Comm.rccl) with world = 1: keeps the script the multi-GPU test
+    launches exercised on the one-GPU lease"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ECFFT_WORKER_RCCL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 def test_sharded_transforms_over_rccl_single_rank():
     """the C++ sharded path over the REAL RCCL transport (librccl loaded at run time, ncclGetUniqueId / ncclCommInitRank,
     grouped ncclSend / ncclRecv on the HIP stream).  The GPU box has one GPU, so world = 1: every exchange is a self
