@@ -129,7 +129,7 @@ public:
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         f_ = take(2 * N_);
-        ECFFT_HIP_TRY(hipMemcpyAsync(f_, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
+        if (!points_on_device(f_, s)) { fprintf(stderr, "ecfft: point set construction failed\n"); return false; }
         // denominators of the maps: v_k(x) = den0 + den1 x (degree 1 for both curve families)
         std::vector<E> den(2 * (L_ ? L_ : 1));
         for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
@@ -328,9 +328,84 @@ public:
         temps_done();
         return ok ? (long)h : -1;
     }
+    // The point set f (2N elements: layer k at [N >> k, 2*(N >> k))) into fdev: uploaded when the host tree carries it (trees made
+    // from user leaves, ecfft_fftree_new), otherwise COMPUTED HERE from the generator data — the FftreeField::build_fftree front
+    // end (src/lib.rs:66-81, src/ec.rs:545-551) and FFTree::new's layers (src/fftree.rs:42-70) as GPU passes: leaf i = x(off + i*gen)
+    // through log N rounds of batched affine additions P_{r+j} = P_r + P_j (one batched inversion per round), then layer k+1 =
+    // psi_k(layer k) pointwise with a batched inversion of the denominators.  Same field elements as host_curve.h produces (the
+    // host path stays for ecfft_build_points and as the cross-check in the tests); 2^23 points: milliseconds instead of seconds.
+    bool points_on_device(E* fdev, hipStream_t s) {
+        const size_t n = N_;
+        if (!host_.f.empty()) { ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * n * sizeof(E), hipMemcpyHostToDevice, s)); return true; }
+        if (!host_.have_gen) return false;
+        const E a2 = host_.curve.a2, a4 = host_.curve.a4, offx = host_.off.x, offy = host_.off.y;
+        E *px = temp(n), *py = temp(n), *den = temp(n);
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(temp(8));
+        (void)hipMemsetAsync(bad, 0, sizeof(unsigned long long), s);
+        (void)hipMemsetAsync(fdev, 0, n * sizeof(E), s);          // f[0] is unused; the layers below the leaves are written next
+        if (n > 1) {
+            ECFFT_HIP_TRY(hipMemcpyAsync(px + 1, &host_.gen.x, sizeof(E), hipMemcpyHostToDevice, s));
+            ECFFT_HIP_TRY(hipMemcpyAsync(py + 1, &host_.gen.y, sizeof(E), hipMemcpyHostToDevice, s));
+        }
+        for (size_t r = 1; 2 * r <= n && r < n; r <<= 1) {        // compute_leaves (host_curve.h): i*gen for every 0 < i < n
+            const size_t cnt = r - 1;
+            if (cnt) {
+                foreach_n(s, cnt, [=] __device__(size_t t) { den[t] = F::sub(px[t + 1], px[r]); });
+                batch_inv(den, den, cnt, s);
+                foreach_n(s, cnt, [=] __device__(size_t t) {
+                    const size_t j = t + 1;
+                    const E xr = px[r], yr = py[r];
+                    const E lambda = F::mul(F::sub(py[j], yr), den[t]);
+                    const E x3 = F::sub(F::sub(F::sub(F::sqr(lambda), a2), xr), px[j]);
+                    px[r + j] = x3;
+                    py[r + j] = F::sub(F::mul(lambda, F::sub(xr, x3)), yr);
+                });
+            }
+            if (2 * r < n) foreach_n(s, 1, [=] __device__(size_t) {   // P_{2r} = 2 * P_r (pt_add with p == q)
+                const E x = px[r], y = py[r], xx = F::sqr(x);
+                const E num = F::add(F::add(F::add(xx, xx), xx), F::add(F::mul(F::add(a2, a2), x), a4));
+                const E lambda = F::mul(num, F::inv(F::add(y, y)));
+                const E x3 = F::sub(F::sub(F::sub(F::sqr(lambda), a2), x), x);
+                px[2 * r] = x3; py[2 * r] = F::sub(F::mul(lambda, F::sub(x, x3)), y);
+            });
+        }
+        E* leaves = fdev + n;
+        foreach_n(s, 1, [=] __device__(size_t) { leaves[0] = offx; });
+        if (n > 1) {
+            foreach_n(s, n - 1, [=] __device__(size_t t) { den[t] = F::sub(px[t + 1], offx); });
+            batch_inv(den, den, n - 1, s);
+            foreach_n(s, n - 1, [=] __device__(size_t t) {
+                const size_t i = t + 1;
+                const E lambda = F::mul(F::sub(py[i], offy), den[t]);
+                leaves[i] = F::sub(F::sub(F::sub(F::sqr(lambda), a2), offx), px[i]);
+            });
+        }
+        unsigned k = 0;
+        for (size_t sz = n; sz > 1; ++k, sz >>= 1) {              // fill_layers (host_curve.h / src/fftree.rs:42-70)
+            const size_t half = sz / 2;
+            const E* prev = fdev + sz; E* layer = fdev + half;
+            const RatMap<F> m = host_.maps[k];
+            foreach_n(s, half, [=] __device__(size_t j) {
+                const E x = prev[j];
+                const E d = F::mul_add(F::mul_add(m.den[2], x, m.den[1]), x, m.den[0]);
+                if (F::is_zero(d)) atomicAdd(bad, 1ull);
+                den[j] = d;
+            });
+            batch_inv(den, den, half, s);
+            foreach_n(s, half, [=] __device__(size_t j) {
+                const E x = prev[j];
+                layer[j] = F::mul(F::mul_add(F::mul_add(m.num[2], x, m.num[1]), x, m.num[0]), den[j]);
+            });
+        }
+        unsigned long long h = 0;
+        ECFFT_HIP_TRY(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, s));
+        ECFFT_HIP_TRY(hipStreamSynchronize(s));
+        temps_done();
+        return h == 0 && hipGetLastError() == hipSuccess;
+    }
     bool upload_points(E*& fdev, hipStream_t s) {               // the caller hipFree()s fdev
         ECFFT_HIP_TRY(hipMalloc(&fdev, 2 * N_ * sizeof(E)));
-        ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * N_ * sizeof(E), hipMemcpyHostToDevice, s));
+        if (!points_on_device(fdev, s)) { (void)hipFree(fdev); fdev = nullptr; return false; }
         std::vector<E> den(2 * (L_ ? L_ : 1));
         for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
         den_ = take(2 * (L_ ? L_ : 1));

@@ -172,7 +172,10 @@ int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap
     }
     if (which == ECFFT_TBL_F) {
         // f of T_m: every (N/m)-th element of each layer of the top tree (src/fftree.rs:471-478)
-        const std::vector<E>& f = ch.host().f; size_t N = ch.size(), stride = N / m;
+        // the point set lives on the device (computed there for build_fftree contexts)
+        size_t N = ch.size(), stride = N / m;
+        std::vector<E> f(2 * N);
+        if (!ch.f_device() || hipMemcpy(f.data(), ch.f_device(), 2 * N * sizeof(E), hipMemcpyDeviceToHost) != hipSuccess) return ECFFT_ERR_HIP;
         o[0] = F::zero();
         for (size_t sz = m, top = N; sz >= 1; sz >>= 1, top >>= 1) {
             for (size_t j = 0; j < sz; ++j) o[sz + j] = f[top + j * stride];
@@ -493,13 +496,13 @@ int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
     int rc;
     if (field == ECFFT_FIELD_SECP256K1) {
         HostTree<Secp256k1> ht;
-        int r = build_host_tree<Secp256k1>(log_n, ht);
+        int r = build_host_tree<Secp256k1>(log_n, ht, /*points=*/false);   // leaves and layers are computed on the GPU (points_on_device)
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
         rc = guarded([&] { return finish_build(std::move(ht), device, c->secp); });
     } else {
         HostTree<M31> ht;
-        int r = build_host_tree<M31>(log_n, ht);
+        int r = build_host_tree<M31>(log_n, ht, /*points=*/false);   // leaves and layers are computed on the GPU (points_on_device)
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
         rc = guarded([&] { return finish_build(std::move(ht), device, c->m31); });
@@ -540,13 +543,13 @@ int build_shard_ctx(int kind, int field, size_t len, int device, int world, int 
     int rc;
     if (field == ECFFT_FIELD_SECP256K1) {
         HostTree<Secp256k1> ht;
-        int r = build_host_tree<Secp256k1>(log_n, ht);
+        int r = build_host_tree<Secp256k1>(log_n, ht, /*points=*/false);   // leaves and layers are computed on the GPU (points_on_device)
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
         rc = guarded([&] { return finish(std::move(ht), c->secp); });
     } else {
         HostTree<M31> ht;
-        int r = build_host_tree<M31>(log_n, ht);
+        int r = build_host_tree<M31>(log_n, ht, /*points=*/false);   // leaves and layers are computed on the GPU (points_on_device)
         if (r == 1) return ECFFT_ERR_TREE_TOO_LARGE;
         if (r) return ECFFT_ERR_BAD_ARG;
         rc = guarded([&] { return finish(std::move(ht), c->m31); });

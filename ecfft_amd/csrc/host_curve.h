@@ -2,7 +2,10 @@
 // x-maps and the layers L_{k+1} = psi_k(L_k).  This is the `FftreeField::build_fftree` front end
 // (/root/reference/src/lib.rs:39-85 for secp256k1, src/lib.rs:198-215 + src/ec.rs:498-554 for M31)
 // and `FFTree::new` (src/fftree.rs:42-70).  Construction only — O(n) field operations, done once;
-// the O(n log^2 n) table precompute that follows runs on the GPU (device_tree.h).
+// the O(n log^2 n) table precompute that follows runs on the GPU (device_tree.h).  For ecfft_build_fftree and the shard
+// builders only the O(log n) part runs here (curve, generator, isogeny maps); leaves and layers are then computed by the same
+// formulas on the GPU (DeviceChain::points_on_device).  The full host path below serves ecfft_build_points (hosts without a
+// GPU, the CPU tests that pin it to the oracle and the golden vectors) and is what the GPU point set is compared with.
 //
 // Everything here is in PLAIN (non-Montgomery) form; see field_secp256k1.h.  Sequential affine
 // additions with one inversion each (reference: src/lib.rs:73-78) are replaced by log(n) rounds of
@@ -23,11 +26,22 @@ struct RatMap {  // numerator / denominator coefficients, low -> high (src/utils
     typename F::elem num[3], den[3];
 };
 
+// affine points on y^2 = x^3 + a2 x^2 + a4 x + a6 (a1 = a3 = 0; src/ec.rs:376-424)
+template <class F>
+struct Pt { typename F::elem x, y; bool inf; };
+
+template <class F>
+struct Curve { typename F::elem a2, a4, a6; };
+
 template <class F>
 struct HostTree {  // what FFTree::new derives before from_tree: f layers (heap order, 2n) + maps
     size_t n = 0;
-    std::vector<typename F::elem> f;
+    std::vector<typename F::elem> f;          // empty when the point set is left to the GPU (have_gen)
     std::vector<RatMap<F>> maps;
+    // what the leaves are generated from: leaf i = x(off + i*gen) on `curve` — the device front end (device_tree.h
+    // points_on_device) recomputes leaves and layers from these instead of uploading them
+    bool have_gen = false;
+    Curve<F> curve{}; Pt<F> off{}, gen{};
 };
 
 template <class F>
@@ -66,13 +80,6 @@ static bool fill_layers(HostTree<F>& t) {
     }
     return true;
 }
-
-// ---- affine points on y^2 = x^3 + a2 x^2 + a4 x + a6 (a1 = a3 = 0; src/ec.rs:376-424) ----
-template <class F>
-struct Pt { typename F::elem x, y; bool inf; };
-
-template <class F>
-struct Curve { typename F::elem a2, a4, a6; };
 
 template <class F>
 static Pt<F> pt_add(const Curve<F>& c, const Pt<F>& p, const Pt<F>& q) {
@@ -137,7 +144,8 @@ static void compute_leaves(const Curve<F>& c, const Pt<F>& offset, const Pt<F>& 
 
 // ---- secp256k1: good curve + good isogeny chain (src/ec.rs:38-45, 61-90, 177-189) ----
 // returns 0 ok, 1 = n too large for the curve's 2-adicity (build_fftree -> None), 2 = internal error
-static inline int build_secp256k1(unsigned log_n, HostTree<Secp256k1>& t) {
+// points = false: only the maps and the generator data (the GPU computes leaves and layers)
+static inline int build_secp256k1(unsigned log_n, HostTree<Secp256k1>& t, bool points = true) {
     using F = Secp256k1; using E = F::elem;
     const unsigned two_adicity = 36;
     if (log_n >= two_adicity) return 1;                         // src/lib.rs:62-64
@@ -151,8 +159,9 @@ static inline int build_secp256k1(unsigned log_n, HostTree<Secp256k1>& t) {
               F::from_dec("73754924733368840065089190002333366411120578552679996887076912271884749237510"), false};
     for (unsigned i = 0; i < two_adicity - log_n; ++i) gen = pt_add(c, gen, gen);   // src/lib.rs:67-70
     size_t n = (size_t)1 << log_n;
-    t.n = n; t.f.assign(2 * n, F::zero()); t.maps.resize(log_n);
-    compute_leaves<F>(c, off, gen, n, t.f.data() + n);
+    t.n = n; t.maps.resize(log_n);
+    t.have_gen = true; t.curve = c; t.off = off; t.gen = gen;
+    if (points) { t.f.assign(2 * n, F::zero()); compute_leaves<F>(c, off, gen, n, t.f.data() + n); }
     for (unsigned k = 0; k < log_n; ++k) {                      // good_isogeny: psi(x) = (x - b)^2 / x
         E b2 = F::sqr(b);
         RatMap<F>& m = t.maps[k];
@@ -164,6 +173,7 @@ static inline int build_secp256k1(unsigned log_n, HostTree<Secp256k1>& t) {
         E b_next; if (!F::sqrt(B_next, &b_next)) return 2;
         a = a_next; b = b_next;
     }
+    if (!points) return 0;
     return fill_layers<F>(t) ? 0 : 2;
 }
 
@@ -229,7 +239,7 @@ static inline std::vector<uint32_t> cubic_roots(uint32_t a, uint32_t b) {
 }
 }  // namespace m31detail
 
-static inline int build_m31(unsigned log_n, HostTree<M31>& t) {
+static inline int build_m31(unsigned log_n, HostTree<M31>& t, bool points = true) {
     using F = M31;
     const unsigned two_adicity = 28;
     if (log_n > two_adicity) return 1;                          // src/ec.rs:513-515
@@ -238,7 +248,8 @@ static inline int build_m31(unsigned log_n, HostTree<M31>& t) {
     Pt<F> off{1048755163u, 279503108u, false}, gen{1273083559u, 804329170u, false};
     for (unsigned i = 0; i < two_adicity - log_n; ++i) gen = pt_add(c, gen, gen);
     size_t n = (size_t)1 << log_n;
-    t.n = n; t.f.assign(2 * n, 0); t.maps.resize(log_n);
+    t.n = n; t.maps.resize(log_n);
+    t.have_gen = true; t.curve = c; t.off = off; t.gen = gen;
     Pt<F> g = gen; Curve<F> cur = c;
     for (unsigned k = 0; k < log_n; ++k) {                      // src/ec.rs:526-543
         std::vector<uint32_t> roots = m31detail::cubic_roots(cur.a4, cur.a6);
@@ -261,12 +272,14 @@ static inline int build_m31(unsigned log_n, HostTree<M31>& t) {
         }
         if (!found) { fprintf(stderr, "ecfft: cannot find a suitable isogeny\n"); return 2; }
     }
+    if (!points) return 0;
+    t.f.assign(2 * n, 0);
     compute_leaves<F>(c, off, gen, n, t.f.data() + n);
     return fill_layers<F>(t) ? 0 : 2;
 }
 
-template <class F> int build_host_tree(unsigned log_n, HostTree<F>& t);
-template <> inline int build_host_tree<Secp256k1>(unsigned log_n, HostTree<Secp256k1>& t) { return build_secp256k1(log_n, t); }
-template <> inline int build_host_tree<M31>(unsigned log_n, HostTree<M31>& t) { return build_m31(log_n, t); }
+template <class F> int build_host_tree(unsigned log_n, HostTree<F>& t, bool points = true);
+template <> inline int build_host_tree<Secp256k1>(unsigned log_n, HostTree<Secp256k1>& t, bool points) { return build_secp256k1(log_n, t, points); }
+template <> inline int build_host_tree<M31>(unsigned log_n, HostTree<M31>& t, bool points) { return build_m31(log_n, t, points); }
 
 }  // namespace ecfft

@@ -360,3 +360,25 @@ def test_one_context_from_two_threads_and_streams(gpu, gpu_tree, oracle_tree):
     assert not errs, errs
     for i in range(2):
         assert np.array_equal(got[i][0], want[i]) and np.array_equal(got[i][1], xs[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,n", [("secp256k1", 1 << 17), ("m31", 1 << 20), ("secp256k1", 2), ("m31", 1)])
+def test_device_point_set_equals_host_point_set(field, n):
+    """build_fftree computes leaves and isogeny layers ON THE GPU (DeviceChain::points_on_device: log n rounds of batched affine
+    additions, then one pointwise pass per layer); the host front end (host_curve.h, ecfft_build_points — already pinned to the
+    oracle and the golden vectors by the CPU tests) must give the same 2n field elements"""
+    import ecfft_amd
+    F = ecfft_amd.FIELDS[field]
+    f_host, _, _ = F.build_points(n)
+    tree = F.build_fftree(n)
+    f_dev = tree.table(ecfft_amd.fftree.TBL_F)
+    assert f_dev.shape == f_host.shape
+    assert np.array_equal(f_dev[1:], f_host[1:])
+    # and a tree made from those host leaves (upload path of FFTree::new) transforms identically
+    if n >= 4:
+        _, num, den = F.build_points(n)
+        t2 = F.new_fftree(f_host[n:], num, den)
+        rng = np.random.default_rng(2)
+        x = rng.integers(0, 2**31 - 1, n, dtype=np.uint32) if field == "m31" else np.concatenate([rng.integers(0, 2**64, size=(n, 3), dtype=np.uint64), rng.integers(0, 2**62, size=(n, 1), dtype=np.uint64)], axis=1)
+        assert np.array_equal(np.asarray(tree.enter(x)), np.asarray(t2.enter(x)))
