@@ -336,13 +336,18 @@ public:
     // host path stays for ecfft_build_points and as the cross-check in the tests); 2^23 points: milliseconds instead of seconds.
     bool points_on_device(E* fdev, hipStream_t s) {
         const size_t n = N_;
-        if (!host_.f.empty()) { ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * n * sizeof(E), hipMemcpyHostToDevice, s)); return true; }
-        if (!host_.have_gen) return false;
+        if (!host_.f.empty() && !host_.leaves_only) { ECFFT_HIP_TRY(hipMemcpyAsync(fdev, host_.f.data(), 2 * n * sizeof(E), hipMemcpyHostToDevice, s)); return true; }
+        if (!host_.have_gen && !host_.leaves_only) return false;
         const E a2 = host_.curve.a2, a4 = host_.curve.a4, offx = host_.off.x, offy = host_.off.y;
-        E *px = temp(n), *py = temp(n), *den = temp(n);
+        E* den = temp(n);
         unsigned long long* bad = reinterpret_cast<unsigned long long*>(temp(8));
         (void)hipMemsetAsync(bad, 0, sizeof(unsigned long long), s);
         (void)hipMemsetAsync(fdev, 0, n * sizeof(E), s);          // f[0] is unused; the layers below the leaves are written next
+        E* leaves = fdev + n;
+        if (host_.leaves_only) {
+            ECFFT_HIP_TRY(hipMemcpyAsync(leaves, host_.f.data() + n, n * sizeof(E), hipMemcpyHostToDevice, s));
+        } else {
+        E *px = temp(n), *py = temp(n);
         if (n > 1) {
             ECFFT_HIP_TRY(hipMemcpyAsync(px + 1, &host_.gen.x, sizeof(E), hipMemcpyHostToDevice, s));
             ECFFT_HIP_TRY(hipMemcpyAsync(py + 1, &host_.gen.y, sizeof(E), hipMemcpyHostToDevice, s));
@@ -369,7 +374,6 @@ public:
                 px[2 * r] = x3; py[2 * r] = F::sub(F::mul(lambda, F::sub(x, x3)), y);
             });
         }
-        E* leaves = fdev + n;
         foreach_n(s, 1, [=] __device__(size_t) { leaves[0] = offx; });
         if (n > 1) {
             foreach_n(s, n - 1, [=] __device__(size_t t) { den[t] = F::sub(px[t + 1], offx); });
@@ -379,6 +383,7 @@ public:
                 const E lambda = F::mul(F::sub(py[i], offy), den[t]);
                 leaves[i] = F::sub(F::sub(F::sub(F::sqr(lambda), a2), offx), px[i]);
             });
+        }
         }
         unsigned k = 0;
         for (size_t sz = n; sz > 1; ++k, sz >>= 1) {              // fill_layers (host_curve.h / src/fftree.rs:42-70)
@@ -401,8 +406,10 @@ public:
         ECFFT_HIP_TRY(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, s));
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
         temps_done();
+        bad_points_ = h != 0;                                      // a leaf is a pole of its isogeny map: not a valid point set
         return h == 0 && hipGetLastError() == hipSuccess;
     }
+    bool bad_points() const { return bad_points_; }
     bool upload_points(E*& fdev, hipStream_t s) {               // the caller hipFree()s fdev
         ECFFT_HIP_TRY(hipMalloc(&fdev, 2 * N_ * sizeof(E)));
         if (!points_on_device(fdev, s)) { (void)hipFree(fdev); fdev = nullptr; return false; }
@@ -1725,6 +1732,7 @@ private:
     std::mutex mu_;
     mutable Profiler prof_;
     hipStream_t sides_[kMaxSides] = {}; hipEvent_t ev_fork_[kMaxSides] = {}, ev_join_[kMaxSides] = {}; int nside_ = 0;
+    bool bad_points_ = false;
     int shard_kind_ = kShardNone;                           // sharded EXTEND-only / ENTER-only context (build_*_shard)
     unsigned shard_log_p_ = 0, shard_rank_ = 0;
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)

@@ -49,7 +49,8 @@ int finish_build(HostTree<F>&& ht, int device, std::unique_ptr<DeviceChain<F>>& 
     if (!slot) return ECFFT_ERR_HIP;
     DeviceGuard dev(device);
     if (!dev.ok) return ECFFT_ERR_HIP;
-    return slot->build(std::move(ht), device) ? ECFFT_OK : ECFFT_ERR_HIP;
+    if (slot->build(std::move(ht), device)) return ECFFT_OK;
+    return slot->bad_points() ? ECFFT_ERR_BAD_ARG : ECFFT_ERR_HIP;       // a leaf that is a pole of its isogeny map is a caller error
 }
 
 // plain <-> crate representation on host buffers
@@ -588,7 +589,7 @@ int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_nu
             secp_from_mont_host(ht.maps[k].num, 3); secp_from_mont_host(ht.maps[k].den, 3);
             if (!Secp256k1::is_zero(ht.maps[k].den[2])) return ECFFT_ERR_BAD_ARG;   // x-map denominators have degree 1
         }
-        if (!fill_layers<Secp256k1>(ht)) return ECFFT_ERR_BAD_ARG;
+        ht.leaves_only = true;                                     // the layers psi_k(L_k) are computed on the GPU (points_on_device)
         rc = guarded([&] { return finish_build(std::move(ht), device, c->secp); });
     } else {
         HostTree<M31> ht; ht.n = n; ht.f.assign(2 * n, 0); ht.maps.resize(log_n);
@@ -597,7 +598,7 @@ int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_nu
             memcpy(ht.maps[k].num, (const char*)map_num3 + 12 * k, 12); memcpy(ht.maps[k].den, (const char*)map_den3 + 12 * k, 12);
             if (ht.maps[k].den[2] != 0) return ECFFT_ERR_BAD_ARG;
         }
-        if (!fill_layers<M31>(ht)) return ECFFT_ERR_BAD_ARG;
+        ht.leaves_only = true;
         rc = guarded([&] { return finish_build(std::move(ht), device, c->m31); });
     }
     if (rc != ECFFT_OK) return rc;

@@ -42,6 +42,7 @@ struct HostTree {  // what FFTree::new derives before from_tree: f layers (heap 
     // points_on_device) recomputes leaves and layers from these instead of uploading them
     bool have_gen = false;
     Curve<F> curve{}; Pt<F> off{}, gen{};
+    bool leaves_only = false;                 // f holds the leaves (f[n..2n)) only: the layers are computed on the GPU (FFTree::new)
 };
 
 template <class F>

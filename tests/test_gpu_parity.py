@@ -382,3 +382,22 @@ def test_device_point_set_equals_host_point_set(field, n):
         rng = np.random.default_rng(2)
         x = rng.integers(0, 2**31 - 1, n, dtype=np.uint32) if field == "m31" else np.concatenate([rng.integers(0, 2**64, size=(n, 3), dtype=np.uint64), rng.integers(0, 2**62, size=(n, 1), dtype=np.uint64)], axis=1)
         assert np.array_equal(np.asarray(tree.enter(x)), np.asarray(t2.enter(x)))
+
+
+@pytest.mark.gpu
+def test_fftree_new_rejects_a_leaf_that_is_a_pole():
+    """FFTree::new with a leaf on which an isogeny map has a pole: the layers are computed on the GPU, the vanishing
+    denominator is detected there and reported as a caller error (the host path returned ECFFT_ERR_BAD_ARG too)"""
+    import ctypes
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS["m31"]
+    n = 64
+    f, num, den = F.build_points(n)
+    leaves = f[n:].copy()
+    p = 2**31 - 1
+    d0, d1 = int(den[0]), int(den[1])
+    leaves[5] = (-d0 * pow(d1, p - 2, p)) % p                      # root of the first map's denominator
+    h = ctypes.c_void_p()
+    rc = FT.lib().ecfft_fftree_new(F.id, leaves.ctypes.data, n, num.ctypes.data, den.ctypes.data, 0, ctypes.byref(h))
+    assert rc == FT.ERR_BAD_ARG and not h.value
