@@ -125,7 +125,7 @@ public:
         // arena per tree of m leaves: 6m elements of reference tables (xnn, z*) + 11m table constants of the hot path
         // (F::telem each); + f (2N) + den coefficients
         size_t total = 2 * N_ + 64;
-        for (unsigned l = 0; l <= L_; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
+        for (unsigned l = 0; l <= L_; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         f_ = take(2 * N_);
@@ -461,7 +461,7 @@ public:
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
         size_t total = 64 + 2 * L_ + 4096;
-        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
+        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
         total += log_p * (shard_set_elems(c, 1) + c + 64);
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
@@ -526,7 +526,7 @@ public:
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
         size_t total = 64 + 3 * L_ + 4096;
-        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024;
+        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
         total += log_p * (shard_set_elems(hc) + 5 * c + 256);
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
@@ -757,15 +757,19 @@ public:
                 // per thread: only valid when the default tile IS such a chunk (non-default ECFFT_LOG_TILE_BYTES / ECFFT_BLOCK_ROW
                 // builds fall back to the run-time-tile kernel)
                 constexpr bool ct_row = sizeof(E) == 4 ? ((size_t)1 << kLogTileMax) == (size_t)kBlockRow * 16 : (ECFFT_CT_ALL != 0);
+                // matrix-core form of the stages with pair distance <= 8 (mfma_blk16.h): whole 1024-element sub-tiles, >= 4 in-tile stages
+                const bool use_blk16 = sizeof(E) == 32 && kBlockRow == 512 && !mfma_off_ && T.blk16_A[srcpar] && log_tile >= 10 && le - k_first >= 4;
+                const uint8_t* bA = use_blk16 ? T.blk16_A[srcpar] : nullptr;
+                const unsigned long long* bK = use_blk16 ? T.blk16_K[srcpar] : nullptr;
                 if (log_tile == kLogTileMax + 1 && ct_row)
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
                 else if (log_tile == kLogTileMax && ct_row)   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
                 else
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, 0>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
-                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar]);
+                                 ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
             } else {
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;           // column tiles may be larger than row tiles
                 if (small && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
@@ -1540,6 +1544,21 @@ private:
         if (le == 0) (void)hipMemcpyAsync(out, Q, m * sizeof(E), hipMemcpyDeviceToDevice, s);
     }
 
+    // matrix-core tables of the innermost 16-point map (mfma_blk16.h), per source parity: 32-byte fields, trees with e >= 16
+    static size_t blk16_elems(unsigned l) { return (sizeof(E) == 32 && l >= 5) ? 2 * (Blk16::kArenaElems + 8) : 0; }
+    void build_blk16(Tree& T, hipStream_t s) {
+        T.blk16_A[0] = T.blk16_A[1] = nullptr; T.blk16_K[0] = T.blk16_K[1] = nullptr;
+        if constexpr (sizeof(E) == 32) {
+            if (T.e < 16) return;
+            for (int sg = 0; sg < 2; ++sg) {
+                uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
+                unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
+                hipLaunchKernelGGL(k_blk16_build, dim3(1), dim3(256), 0, s, T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], T.e, A, K);
+                T.blk16_A[sg] = A; T.blk16_K[sg] = K;
+            }
+        }
+    }
+
     bool build_tree(unsigned l, hipStream_t s) {
         Tree& T = trees_[l];
         size_t m = (size_t)1 << l, e = m / 2;
@@ -1622,6 +1641,7 @@ private:
             T.np0[sg] = to_tables(hnp0[sg], es, s); T.dinv[sg] = to_tables(hdinv[sg], es, s);
             T.w[sg] = to_tables(hw[sg], es, s); T.winv[sg] = to_tables(hwinv[sg], es, s);
         }
+        build_blk16(T, s);
         T.z0_s1 = take(es); T.z1_s0 = take(es); T.z0_inv_s1 = take(es); T.z1_inv_s0 = take(es);
         T.z0z0 = take(m); T.z1z1 = take(m);
         if (l == 1) {                                          // base cases src/fftree.rs:399-403, 454-458
@@ -1738,6 +1758,7 @@ private:
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
+    bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };
 

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <type_traits>
+#include "mfma_blk16.h"
 
 namespace ecfft {
 
@@ -561,7 +562,10 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                                                            const typename F::telem* __restrict__ p1,
                                                            const typename F::telem* __restrict__ inner,
                                                            uint32_t log_e, uint32_t k_first, uint32_t log_tile,
-                                                           const typename F::telem* __restrict__ c0t) {
+                                                           const typename F::telem* __restrict__ c0t,
+                                                           const uint8_t* __restrict__ blkA, const unsigned long long* __restrict__ blkK) {
+    // blkA / blkK != nullptr (32-byte field, tiles of whole 1024-element sub-tiles, >= 4 in-tile stages): the stages with pair
+    // distance <= 8 run on the int8 matrix cores as one 16 x 16 map per block (mfma_blk16.h) instead of 7 VALU sweeps
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
     E* tile = reinterpret_cast<E*>(ecfft_smem);
@@ -594,12 +598,22 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     // stages k_first .. log_e-2 (h >= 2); the two innermost stages (decompose h=1, recombine h=1) act on the
     // same pairs back to back and are merged into out_j = a + c_j*(b - a): 2 multiplies instead of 4
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
-    for (uint32_t k = k_first; k < k_inner; ++k) {
+    bool mfma = false;
+    if constexpr (sizeof(E) == 32 && kBlockRow == 512) mfma = blkA != nullptr;
+    const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;              // mfma: VALU sweeps only for pair distances >= 16
+    for (uint32_t k = k_first; k < k_dec_end; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid, c0t ? c0t + (e - 2 * (size_t)h) : nullptr);
         __syncthreads();
     }
-    if (log_e > 0) {
+    if constexpr (sizeof(E) == 32 && kBlockRow == 512) {
+        if (mfma) {
+            Blk16::to_operand_form<kBlockRow>(tile, T, tid);
+#pragma unroll 1
+            for (uint32_t o = 0; o < T; o += Blk16::kSub) Blk16::phase(tile + o, blkA, blkK, tid);
+        }
+    }
+    if (log_e > 0 && !mfma) {
         if (sizeof(E) == 32 && 2 * npairs <= (uint32_t)kBlockRow) {        // pair-split merged innermost stage
             const bool act = tid < 2 * npairs, hi = tid >= npairs;
             const uint32_t g = hi ? tid - npairs : tid;
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         }
         __syncthreads();
     }
-    for (uint32_t k = k_inner; k-- > k_first;) {
+    for (uint32_t k = k_dec_end; k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
@@ -995,6 +1009,9 @@ struct LevelTables {
     TE *inner[2];   // inner[srcpar] = {c0, c1}: the merged innermost (h = 1) decompose+recombine stage, out_j = a + c_j*(b - a)
     TE *c0t[2];     // c0t[s] = np0[s]*dinv[s]: decompose as two INDEPENDENT multiplies, q0 = a + c0t*(b - a), q1 = dinv*(b - a) (pair-split sweeps)
     E *xnn, *xnn_inv, *z0_s1, *z1_s0, *z0_inv_s1, *z1_inv_s0, *z0z0, *z1z1;
+    // blk16_A[srcpar] / blk16_K[srcpar]: the innermost 16-point map of an EXTEND from parity srcpar as int8 matrices + accumulator
+    // seeds for the matrix cores (mfma_blk16.h); nullptr: the VALU sweeps run (4-byte fields, trees with e < 16, shard contexts)
+    const uint8_t* blk16_A[2]; const unsigned long long* blk16_K[2];
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,276 @@
+// The innermost butterfly stages of the secp256k1 EXTEND on the int8 matrix cores (gfx950 v_mfma_i32_32x32x32_i8).
+//
+// Replaces, inside an LDS tile, the arithmetic of /root/reference/src/utils.rs:338-347 (Mat2x2 * [F;2]) for the stages whose
+// constants are shared by >= 32 butterflies of the tile: the decompose stages with pair distance h = 8, 4, 2, the merged
+// innermost pair (h = 1) and the recombine stages h = 2, 4, 8 (src/fftree.rs:83-118 for the last four levels of the recursion).
+// On every aligned block of 16 points those 7 sweeps are ONE linear map  out_o = sum_i T[o][i] * x_i  (mod p)  with a
+// 16 x 16 matrix of field constants that depends only on the tree and the source parity (stage tables are indexed by
+// position mod h).  Every multiply on the path is data x constant, so each constant c = T[o][i] can be
+// stored as the 32 x 32 int8 matrix
+//        C[b][j] = digit b (radix 256, SIGNED, in [-128, 127]) of  c * 2^(8j) mod p          (j = data byte, b = result digit)
+// and then, for data x = sum_j x_j 2^(8j),     c * x  ==  sum_b 2^(8b) * sum_j C[b][j] * x_j      (mod p):
+// a 32x32x32 int8 contraction per constant and per 32 data elements.  One MFMA takes the same constant for the same
+// position of 32 different blocks (N = 32), 16 MFMAs accumulate the 16 inputs of a block into one 32 x 32 int32 tile, and
+// what is left for the integer VALU is ONE carry normalisation per output element (32 column sums < 2^24 -> eight 32-bit words,
+// fold of the 19-bit top by 2^256 = 2^32 + 977) instead of seven 169-instruction modular multiplies.
+// Data bytes are unsigned; the MFMA is signed x signed: x_j - 128 (xor 0x80) goes in, and 128 * sum_j C[b][j] is part of
+// the per-output constants K.  Results are canonical residues, so the re-association is bit-exact (tools/ubench/mfma_mul.hip
+// checks the scheme against host arithmetic; profiles/r03/ubench_mfma_mul*.txt has the measured rates).
+//
+// Layouts (fixed by the instruction, cdna_hip_programming.md section 3):
+//   A operand (constants): lane l holds row m = l & 31, bytes k = 16*(l >> 5) .. +15;   B operand (data): lane l holds
+//   column n = l & 31 (= block), the same k range = bytes 16*(l >> 5).. of the element;   D: lane l holds column l & 31,
+//   rows (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = register 0..15.  Row m carries result digit b(m) = 16*((m >> 2) & 1) + (m & 3)
+//   + 4*(m >> 3), so that after one v_permlane32_swap per register a lane owns all 32 digits of ONE element: D1[r] = digit r,
+//   D2[r] = digit 16 + r.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "field_secp256k1.h"
+
+namespace ecfft {
+
+struct Blk16 {
+    using F = Secp256k1;
+    using E = Fe256;
+    using TE = Te256;
+    static constexpr int NB = 16;                          // points of the composite map
+    static constexpr size_t kABytes = (size_t)NB * NB * 1024;   // 256 int8 matrices
+    static constexpr size_t kKWords = (size_t)NB * 8;      // per output: eight 64-bit accumulator seeds
+    static constexpr size_t kArenaElems = (kABytes + kKWords * 8) / sizeof(E);   // per (tree, parity), in field elements
+    static constexpr int kSub = 1024;                      // elements per MFMA phase (32 blocks x 2 batches): 512 threads
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+
+    // 16-byte chunk q = 2*j + half of element j -> physical chunk.  The operand reads take the SAME half of 32 elements 16
+    // apart (512 B stride: one bank); xor-ing the chunk's low 4 bits with the block index spreads them over all banks.
+    __host__ __device__ static inline uint32_t phys(uint32_t j, uint32_t hh) {
+        const uint32_t q = 2 * j + hh;
+        return (q & ~15u) | ((q ^ (j >> 4)) & 15u);
+    }
+    // row of the constant matrix that carries result digit b (inverse of b(m) above)
+    __host__ __device__ static inline uint32_t row_of_digit(uint32_t b) {
+        const uint32_t r = b & 15u;
+        return (r & 3u) | ((b >> 4) << 2) | ((r >> 2) << 3);
+    }
+
+    // 32 signed column sums (digit b = lo[b] for b < 16, hi[b - 16] above) + the output's seeds K -> canonical residue
+    __device__ static __forceinline__ E normalise(const int (&lo)[16], const int (&hi)[16], const unsigned long long* __restrict__ K) {
+        long long W[8];
+        const uint32_t s8 = 1u << 8, s16 = 1u << 16, s24 = 1u << 24;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int* y = g < 4 ? &lo[4 * g] : &hi[4 * (g - 4)];
+            const unsigned long long kg = K[g];            // wave-uniform: scalar load
+            long long w;
+            asm("v_mad_i64_i32 %0, vcc, %1, 1, %5\n\t"
+                "v_mad_i64_i32 %0, vcc, %2, %6, %0\n\t"
+                "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\t"
+                "v_mad_i64_i32 %0, vcc, %4, %8, %0"
+                : "=&v"(w) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "s"(kg), "s"(s8), "s"(s16), "s"(s24) : "vcc");
+            W[g] = w;                                      // in [2^50 - 2^48, 2^50 + 2^48 + 2^32)
+        }
+        uint32_t z0 = (uint32_t)W[0], z1, z2, z3, z4, z5, z6, z7, z8, t, c8;
+        uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+        const uint32_t k977 = 977u;
+        // words of sum_g W_g 2^(32g) (z8 < 2^19 + 1), then the fold z8 * (2^32 + 977) onto words 0, 1 and its ripple
+        asm("v_add_co_u32_e32 %0, vcc, %18, %19\n\t"
+            "v_addc_co_u32_e32 %1, vcc, %20, %21, vcc\n\t"
+            "v_addc_co_u32_e32 %2, vcc, %22, %23, vcc\n\t"
+            "v_addc_co_u32_e32 %3, vcc, %24, %25, vcc\n\t"
+            "v_addc_co_u32_e32 %4, vcc, %26, %27, vcc\n\t"
+            "v_addc_co_u32_e32 %5, vcc, %28, %29, vcc\n\t"
+            "v_addc_co_u32_e32 %6, vcc, %30, %31, vcc\n\t"
+            "v_addc_co_u32_e32 %7, vcc, 0, %32, vcc\n\t"
+            "v_mul_u32_u24_e32 %8, %34, %7\n\t"
+            "v_add_co_u32_e32 %9, vcc, %33, %8\n\t"
+            "v_addc_co_u32_e32 %10, vcc, %0, %7, vcc\n\t"
+            "v_addc_co_u32_e32 %11, vcc, 0, %1, vcc\n\t"
+            "v_addc_co_u32_e32 %12, vcc, 0, %2, vcc\n\t"
+            "v_addc_co_u32_e32 %13, vcc, 0, %3, vcc\n\t"
+            "v_addc_co_u32_e32 %14, vcc, 0, %4, vcc\n\t"
+            "v_addc_co_u32_e32 %15, vcc, 0, %5, vcc\n\t"
+            "v_addc_co_u32_e32 %16, vcc, 0, %6, vcc\n\t"
+            "v_addc_co_u32_e64 %17, vcc, 0, 0, vcc"
+            : "=&v"(z1), "=&v"(z2), "=&v"(z3), "=&v"(z4), "=&v"(z5), "=&v"(z6), "=&v"(z7), "=&v"(z8), "=&v"(t),
+              "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(c8)
+            : "v"((uint32_t)((unsigned long long)W[0] >> 32)), "v"((uint32_t)W[1]),
+              "v"((uint32_t)((unsigned long long)W[1] >> 32)), "v"((uint32_t)W[2]),
+              "v"((uint32_t)((unsigned long long)W[2] >> 32)), "v"((uint32_t)W[3]),
+              "v"((uint32_t)((unsigned long long)W[3] >> 32)), "v"((uint32_t)W[4]),
+              "v"((uint32_t)((unsigned long long)W[4] >> 32)), "v"((uint32_t)W[5]),
+              "v"((uint32_t)((unsigned long long)W[5] >> 32)), "v"((uint32_t)W[6]),
+              "v"((uint32_t)((unsigned long long)W[6] >> 32)), "v"((uint32_t)W[7]),
+              "v"((uint32_t)((unsigned long long)W[7] >> 32)), "v"(z0), "s"(k977)
+            : "vcc");
+        E r; r.l[0] = r0; r.l[1] = r1; r.l[2] = r2; r.l[3] = r3; r.l[4] = r4; r.l[5] = r5; r.l[6] = r6; r.l[7] = r7;
+        // a carry out of word 7 (needs words 2..7 all ones) or a value in [p, 2^256) (needs word 7 all ones): ~2^-32
+        if (__builtin_expect(c8 | (uint32_t)(r7 == 0xFFFFFFFFu), 0)) {
+            uint32_t sv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[i] = r.l[i];
+            r = F::finish(sv, c8);
+        }
+        return r;
+    }
+
+    // plain tile (T elements, T a multiple of 512) -> operand form: bytes xor 0x80, chunks swizzled.  Ends with a barrier.
+    template <int BLK>
+    __device__ static __forceinline__ void to_operand_form(E* tile, uint32_t T, uint32_t tid) {
+        uint4* lds = reinterpret_cast<uint4*>(tile);
+#pragma unroll 1
+        for (uint32_t base = 0; base < T; base += 2 * BLK) {       // 2 elements per thread per round
+            const uint32_t j0 = base + tid, j1 = base + BLK + tid;
+            const bool two = j1 < T;
+            uint4 a0 = lds[2 * j0], a1 = lds[2 * j0 + 1], b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+            if (two) { b0 = lds[2 * j1]; b1 = lds[2 * j1 + 1]; }
+            __syncthreads();
+            const uint32_t X = 0x80808080u;
+            lds[phys(j0, 0)] = make_uint4(a0.x ^ X, a0.y ^ X, a0.z ^ X, a0.w ^ X);
+            lds[phys(j0, 1)] = make_uint4(a1.x ^ X, a1.y ^ X, a1.z ^ X, a1.w ^ X);
+            if (two) { lds[phys(j1, 0)] = make_uint4(b0.x ^ X, b0.y ^ X, b0.z ^ X, b0.w ^ X); lds[phys(j1, 1)] = make_uint4(b1.x ^ X, b1.y ^ X, b1.z ^ X, b1.w ^ X); }
+        }
+        __syncthreads();
+    }
+
+    // The map on the 64 blocks of one 1024-element sub-tile held in operand form; results are written back PLAIN (canonical
+    // residues in the ordinary element layout).  512 threads: wave w produces outputs o = 2w, 2w+1 of all 64 blocks — four
+    // 32 x 32 accumulators, so every data operand is read from LDS once per wave, and the operands of input i+1 (two constant
+    // matrices from L2, two data operands from LDS) are requested before the four MFMAs of input i issue.
+    // Ends with a barrier.
+    __device__ static __forceinline__ void phase(E* sub, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid) {
+        uint4* lds = reinterpret_cast<uint4*>(sub);
+        const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 31, h = L >> 5;
+        typedef const __attribute__((address_space(1))) char* gchar;
+        typedef const __attribute__((address_space(1))) v4i* gv4;
+        const gchar ap = (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(2 * w) * NB) * 1024 + L * 16;
+        auto ldA = [&](int oo, int i) { return *(gv4)(ap + ((size_t)oo * NB + (size_t)i) * 1024); };
+        // operand address of (block, input i): phys() reduces to a0 ^ 32*i bytes (2i | h never carries), batch 1 is 16 KiB above
+        const uint32_t a0 = 16u * phys(n * NB, h);
+        const char* lb = reinterpret_cast<const char*>(lds);
+        auto ldB = [&](int r, int i) { const uint4 b = *reinterpret_cast<const uint4*>(lb + ((a0 ^ (32u * (uint32_t)i)) + 16384u * (uint32_t)r)); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
+        v16i acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};           // acc[output][batch]
+        v4i A0 = ldA(0, 0), A1 = ldA(1, 0), B0 = ldB(0, 0), B1 = ldB(1, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            v4i nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
+#if defined(BLK16_EXP) && BLK16_EXP == 1      // experiment: no constant-matrix traffic
+            if (i + 1 < NB) { nB0 = ldB(0, i + 1); nB1 = ldB(1, i + 1); }
+#elif defined(BLK16_EXP) && BLK16_EXP == 3    // experiment: no LDS operand traffic
+            if (i + 1 < NB) { nA0 = ldA(0, i + 1); nA1 = ldA(1, i + 1); }
+#else
+            if (i + 1 < NB) { nA0 = ldA(0, i + 1); nA1 = ldA(1, i + 1); nB0 = ldB(0, i + 1); nB1 = ldB(1, i + 1); }
+#endif
+            __builtin_amdgcn_sched_barrier(0);          // keep the requests ABOVE the MFMAs (the scheduler sinks them to their uses)
+#if defined(BLK16_EXP) && BLK16_EXP == 2      // experiment: no MFMA
+            acc00[i] += A0[0] ^ B0[1]; acc01[i] += A0[1] ^ B1[2]; acc10[i] += A1[2] ^ B0[3]; acc11[i] += A1[3] ^ B1[0];
+#else
+            acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B1, acc11, 0, 0, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+        }
+        E outz[2];
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) {
+            int lo[16], hi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                auto p = __builtin_amdgcn_permlane32_swap((unsigned)(oo ? acc10[r] : acc00[r]), (unsigned)(oo ? acc11[r] : acc01[r]), false, false);
+                lo[r] = (int)p[0]; hi[r] = (int)p[1];
+            }
+            outz[oo] = normalise(lo, hi, Kc + (2 * w + oo) * 8);
+        }
+        __syncthreads();        // every operand read of this phase is done: the tile can be overwritten
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) {
+            const uint32_t j = L * NB + 2 * w + oo;           // lane L holds block L (batch L >> 5, column L & 31)
+            const E& z = outz[oo];
+            lds[2 * j] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);
+            lds[2 * j + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- construction: the 16 x 16 matrix of the tree (the kernels' own stage code applied to the unit vectors), its
+    // int8 expansion and the accumulator seeds.  One workgroup of 256 threads per (tree, parity).
+    __device__ static inline void signed_digits(const E& c, int8_t d[32]) {
+        // value c or c - p, whichever lies in [-0x8080..80, 0x7f7f..7f]: digits of (pattern + 0x8080..80) xor 0x80
+        bool big = false, decided = false;
+        for (int i = 7; i >= 0; --i) { if (!decided && c.l[i] != 0x7f7f7f7fu) { big = c.l[i] > 0x7f7f7f7fu; decided = true; } }
+        uint32_t wv[8];
+        uint64_t cy = big ? 977u : 0u;
+        for (int i = 0; i < 8; ++i) { cy += (uint64_t)c.l[i] + ((big && i == 1) ? 1u : 0u); wv[i] = (uint32_t)cy; cy >>= 32; }
+        cy = 0;
+        for (int i = 0; i < 8; ++i) { cy += (uint64_t)wv[i] + 0x80808080u; wv[i] = (uint32_t)cy; cy >>= 32; }
+        for (int j = 0; j < 32; ++j) d[j] = (int8_t)(((wv[j >> 2] >> (8 * (j & 3))) & 0xffu) ^ 0x80u);
+    }
+};
+
+// np0 / dinv: decompose tables of the source parity, p0 / p1: recombine tables of the target parity, inner: merged innermost
+// pair (all as the row kernel receives them), e = vector length of the tree (>= 16)
+__global__ __launch_bounds__(256) void k_blk16_build(const Te256* __restrict__ np0, const Te256* __restrict__ dinv, const Te256* __restrict__ p0,
+                                                     const Te256* __restrict__ p1, const Te256* __restrict__ inner, size_t e,
+                                                     uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc) {
+    using F = Secp256k1; using E = Fe256;
+    __shared__ E Tm[256];
+    __shared__ E csum[256];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 16) {
+        E x[16];
+        for (int k = 0; k < 16; ++k) x[k] = (k == (int)tid) ? F::one() : F::zero();
+        for (int lh = 3; lh >= 1; --lh) {
+            const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
+            for (uint32_t g = 0; g < 8; ++g) {
+                const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+                const E a = x[idx], b = x[idx + h];
+                const E q1 = F::tmul(dinv[off + i], F::sub(b, a));
+                x[idx] = F::tmul_add(np0[off + i], q1, a); x[idx + h] = q1;
+            }
+        }
+        {
+            const Te256 c0 = inner[0], c1 = inner[1];
+            for (uint32_t g = 0; g < 8; ++g) { const E a = x[2 * g], d = F::sub(x[2 * g + 1], a); x[2 * g] = F::tmul_add(c0, d, a); x[2 * g + 1] = F::tmul_add(c1, d, a); }
+        }
+        for (int lh = 1; lh <= 3; ++lh) {
+            const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
+            for (uint32_t g = 0; g < 8; ++g) {
+                const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+                const E a = x[idx], b = x[idx + h];
+                x[idx] = F::tmul_add(p0[off + i], b, a); x[idx + h] = F::tmul_add(p1[off + i], b, a);
+            }
+        }
+        for (int o = 0; o < 16; ++o) Tm[o * 16 + tid] = x[o];      // column tid of T
+    }
+    __syncthreads();
+    {
+        const uint32_t o = tid >> 4, i = tid & 15;
+        E c = Tm[tid], sum = F::zero();
+        const E f256 = F::from_u32(256);
+        uint8_t* A = Amat + ((size_t)o * 16 + i) * 1024;
+        for (uint32_t j = 0; j < 32; ++j) {
+            int8_t d[32];
+            Blk16::signed_digits(c, d);
+            const uint32_t hh = j >> 4, q = j & 15;
+            for (uint32_t b = 0; b < 32; ++b) A[(Blk16::row_of_digit(b) + 32 * hh) * 16 + q] = (uint8_t)d[b];
+            sum = F::add(sum, c);
+            c = F::mul(c, f256);
+        }
+        csum[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        E s = F::zero();
+        for (int i = 0; i < 16; ++i) s = F::add(s, csum[tid * 16 + i]);
+        // offsets 2^50 on each of the eight 64-bit accumulators: sum_g 2^(50 + 32g) mod p, with 2^274 = 2^18 (2^32 + 977)
+        E off; off.l[0] = 977u << 18; off.l[1] = 1u << 19; for (int i = 2; i < 8; ++i) off.l[i] = 1u << 18;
+        const E kap = F::sub(F::mul(s, F::from_u32(128)), off);
+        for (int g = 0; g < 8; ++g) Kc[tid * 8 + g] = (1ull << 50) + kap.l[g];
+    }
+}
+
+}  // namespace ecfft

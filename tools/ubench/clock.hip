@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include "../../ecfft_amd/csrc/field_secp256k1.h"
 #include "../../ecfft_amd/csrc/field_m31.h"
 using namespace ecfft;
@@ -42,6 +43,47 @@ KERNEL_BODY(k_mul_lo_u32, DECL32, ALL8(OP3, "v_mul_lo_u32"), FOLD32)
 KERNEL_BODY(k_add_co_addc, DECL32, OPCO(c0) OPCO(c1) OPCO(c2) OPCO(c3) OPCO(c4) OPCO(c5) OPCO(c6) OPCO(c7), FOLD32)
 KERNEL_BODY(k_mad_u64_u32, DECL64, OP_MAD64(c0) OP_MAD64(c1) OP_MAD64(c2) OP_MAD64(c3) OP_MAD64(c4) OP_MAD64(c5) OP_MAD64(c6) OP_MAD64(c7), FOLD64)
 KERNEL_BODY(k_mad_addc, DECL64 uint32_t x = t;, OPMADCO(c0) OPMADCO(c1) OPMADCO(c2) OPMADCO(c3) OPMADCO(c4) OPMADCO(c5) OPMADCO(c6) OPMADCO(c7), (FOLD64) ^ x)
+
+
+// ---- round 3: the instruction classes of the two candidate replacements for the integer table multiply -------------------
+#define DECLF64 double c0=t,c1=t+1,c2=t+2,c3=t+3,c4=t+4,c5=t+5,c6=t+6,c7=t+7; double a=1.0000001, b=1e-9;
+#define OPF64(c) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
+#define OPADDF64(c) asm volatile("v_add_f64 %0, %0, %1" : "+v"(c) : "v"(b));
+#define OP_MADI64(c) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+#define OP_LSHLADD64(c) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(c) : "v"(c7));
+#define OP_SWAP(c) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(a));
+#define OP_MUL24(c) asm volatile("v_mul_u32_u24_e32 %0, %0, %1" : "+v"(c) : "v"(a));
+#define OP_XOR(c) asm volatile("v_xor_b32_e32 %0, %0, %1" : "+v"(c) : "v"(a));
+KERNEL_BODY(k_fma_f64, DECLF64, OPF64(c0) OPF64(c1) OPF64(c2) OPF64(c3) OPF64(c4) OPF64(c5) OPF64(c6) OPF64(c7), (uint32_t)(c0+c1+c2+c3+c4+c5+c6+c7))
+KERNEL_BODY(k_add_f64, DECLF64, OPADDF64(c0) OPADDF64(c1) OPADDF64(c2) OPADDF64(c3) OPADDF64(c4) OPADDF64(c5) OPADDF64(c6) OPADDF64(c7), (uint32_t)(c0+c1+c2+c3+c4+c5+c6+c7))
+KERNEL_BODY(k_mad_i64_i32, DECL64, OP_MADI64(c0) OP_MADI64(c1) OP_MADI64(c2) OP_MADI64(c3) OP_MADI64(c4) OP_MADI64(c5) OP_MADI64(c6) OP_MADI64(c7), FOLD64)
+KERNEL_BODY(k_lshl_add_u64, DECL64, OP_LSHLADD64(c0) OP_LSHLADD64(c1) OP_LSHLADD64(c2) OP_LSHLADD64(c3) OP_LSHLADD64(c4) OP_LSHLADD64(c5) OP_LSHLADD64(c6) OP_LSHLADD64(c0), FOLD64)
+KERNEL_BODY(k_permlane32_swap, DECL32, OP_SWAP(c0) OP_SWAP(c1) OP_SWAP(c2) OP_SWAP(c3) OP_SWAP(c4) OP_SWAP(c5) OP_SWAP(c6) OP_SWAP(c7), FOLD32 ^ a)
+KERNEL_BODY(k_mul_u32_u24, DECL32, ALL8(OP3, "v_mul_u32_u24_e32"), FOLD32)
+KERNEL_BODY(k_xor_b32, DECL32, ALL8(OP3, "v_xor_b32_e32"), FOLD32)
+
+// v_mfma_i32_32x32x32_i8: NACC independent accumulators per wave (1: dependent chain on one accumulator)
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_i8(uint32_t* out, Stamp* st, uint32_t seed) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256 + seed;
+    v4i_t A = {(int)t, (int)(t * 3u), (int)(t * 5u), (int)(t * 7u)}, B = {(int)(t ^ 0x55u), (int)(t * 11u), (int)(t * 13u), (int)(t * 17u)};
+    v16i_t acc[NACC];
+    for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = (int)t + k + r;
+    unsigned long long c_0 = __builtin_amdgcn_s_memtime(), w_0 = wall_clock64();
+#pragma unroll 1
+    for (int it = 0; it < ITER / 8; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8 / NACC; ++u)
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) acc[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[k], 0, 0, 0);
+    }
+    unsigned long long c_1 = __builtin_amdgcn_s_memtime(), w_1 = wall_clock64();
+    uint32_t f = 0; for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) f ^= (uint32_t)acc[k][r];
+    out[threadIdx.x + blockIdx.x * 256] = f;
+    if (threadIdx.x == 0) { st[blockIdx.x].cyc = c_1 - c_0; st[blockIdx.x].wall = w_1 - w_0; }
+}
 
 // the kernels' table multiply (169 instructions) as a dependent chain
 __global__ __launch_bounds__(256) void k_tmul_chain(uint32_t* out, Stamp* st, uint32_t seed) {
@@ -102,6 +144,17 @@ void run(const char* name, K kern, uint32_t* d_out, Stamp* d_st, double ops_per_
 int main() {
     uint32_t* d_out; Stamp* d_st;
     (void)hipMalloc(&d_out, 256 * 8 * 256 * 4); (void)hipMalloc(&d_st, sizeof(Stamp) * 256 * 8);
+    run("v_fma_f64", k_fma_f64, d_out, d_st, 8, ITER);
+    run("v_add_f64", k_add_f64, d_out, d_st, 8, ITER);
+    run("v_mad_i64_i32", k_mad_i64_i32, d_out, d_st, 8, ITER);
+    run("v_lshl_add_u64", k_lshl_add_u64, d_out, d_st, 8, ITER);
+    run("v_permlane32_swap", k_permlane32_swap, d_out, d_st, 8, ITER);
+    run("v_mul_u32_u24", k_mul_u32_u24, d_out, d_st, 8, ITER);
+    run("v_xor_b32", k_xor_b32, d_out, d_st, 8, ITER);
+    run("mfma_i32_32x32x32_i8 x1 (dependent)", k_mfma_i8<1>, d_out, d_st, 8, ITER / 8);
+    run("mfma_i32_32x32x32_i8 x2", k_mfma_i8<2>, d_out, d_st, 8, ITER / 8);
+    run("mfma_i32_32x32x32_i8 x4", k_mfma_i8<4>, d_out, d_st, 8, ITER / 8);
+    if (getenv("CLOCK_R3_ONLY")) return 0;
     run("v_fma_f32", k_fma_f32, d_out, d_st, 8, ITER);
     run("v_add_u32", k_add_u32, d_out, d_st, 8, ITER);
     run("v_mul_lo_u32", k_mul_lo_u32, d_out, d_st, 8, ITER);
