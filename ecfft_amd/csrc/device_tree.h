@@ -764,7 +764,7 @@ public:
                 if (log_tile == kLogTileMax + 1 && ct_row)
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
-                else if (log_tile == kLogTileMax && ct_row)   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
+                else if (log_tile == kLogTileMax && (ct_row || (bA && row_ct_)))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
                 else
@@ -1549,7 +1549,7 @@ private:
     void build_blk16(Tree& T, hipStream_t s) {
         T.blk16_A[0] = T.blk16_A[1] = nullptr; T.blk16_K[0] = T.blk16_K[1] = nullptr;
         if constexpr (sizeof(E) == 32) {
-            if (T.e < 16) return;
+            if (T.e < 16 || mfma_off_) return;
             for (int sg = 0; sg < 2; ++sg) {
                 uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
                 unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
@@ -1758,6 +1758,7 @@ private:
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
+    bool row_ct_ = getenv("ECFFT_NO_ROW_CT") == nullptr;               // matrix-core row passes use the compile-time-tile instantiation (no spills there)
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

@@ -601,16 +601,49 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     bool mfma = false;
     if constexpr (sizeof(E) == 32 && kBlockRow == 512) mfma = blkA != nullptr;
     const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;              // mfma: VALU sweeps only for pair distances >= 16
-    for (uint32_t k = k_first; k < k_dec_end; ++k) {
+    // mfma with T == 1024 and a decompose sweep at distance 16 in this kernel: that sweep writes its results in operand form itself
+    const bool fuse16 = mfma && T == (uint32_t)Blk16::kSub && k_first < k_dec_end;
+    for (uint32_t k = k_first; k < k_dec_end - (fuse16 ? 1u : 0u); ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid, c0t ? c0t + (e - 2 * (size_t)h) : nullptr);
         __syncthreads();
     }
     if constexpr (sizeof(E) == 32 && kBlockRow == 512) {
         if (mfma) {
-            Blk16::to_operand_form<kBlockRow>(tile, T, tid);
+            Blk16::APre pre;
+            if (fuse16) {                                                // one pair per thread: (idx, idx + 16)
+                const uint32_t i = tid & 15u, idx = ((tid >> 4) << 5) + i;
+                const E a = tile[idx], b = tile[idx + 16];
+                const E q1 = F::tmul(ldt(dinv + (e - 32), i), F::sub(b, a));
+                const E q0 = F::tmul_add(ldt(np0 + (e - 32), i), q1, a);
+                __builtin_amdgcn_sched_barrier(0);
+                pre = Blk16::prefetch(blkA, tid);                        // after the multiplies (they need the registers), before the barriers
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                         // operand form permutes chunks across threads' elements
+                Blk16::store_operand(tile, idx, q0); Blk16::store_operand(tile, idx + 16, q1);
+                __syncthreads();
+            } else {
+                pre = Blk16::prefetch(blkA, tid);
+                __builtin_amdgcn_sched_barrier(0);
+                Blk16::to_operand_form<kBlockRow>(tile, T, tid);
+            }
+#ifndef ECFFT_EXP_SKIP_PHASE
 #pragma unroll 1
-            for (uint32_t o = 0; o < T; o += Blk16::kSub) Blk16::phase(tile + o, blkA, blkK, tid);
+            for (uint32_t o = 0; o < T; o += Blk16::kSub) {
+                if (o) { pre = Blk16::prefetch(blkA, tid); __builtin_amdgcn_sched_barrier(0); }
+                Blk16::phase(tile + o, blkA, blkK, tid, pre);
+            }
+#endif
+            if (fuse16) {                                                // recombine sweep at distance 16, reading the swizzled results
+                const uint32_t i = tid & 15u, idx = ((tid >> 4) << 5) + i;
+                const E a = Blk16::load_swizzled(tile, idx), b = Blk16::load_swizzled(tile, idx + 16);
+                const E o0 = F::tmul_add(ldt(p0 + (e - 32), i), b, a), o1 = F::tmul_add(ldt(p1 + (e - 32), i), b, a);
+                __syncthreads();
+                tile[idx] = o0; tile[idx + 16] = o1;
+                __syncthreads();
+            } else {
+                Blk16::from_swizzled<kBlockRow>(tile, T, tid);
+            }
         }
     }
     if (log_e > 0 && !mfma) {
@@ -633,7 +666,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         }
         __syncthreads();
     }
-    for (uint32_t k = k_dec_end; k-- > k_first;) {
+    for (uint32_t k = k_dec_end - (fuse16 ? 1u : 0u); k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();
@@ -1045,7 +1078,9 @@ template <class F, int BLK>
 __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
                                              const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
-                                             const typename F::telem* __restrict__ inner, uint32_t tid) {
+                                             const typename F::telem* __restrict__ inner, uint32_t tid,
+                                             const uint8_t* __restrict__ blkA = nullptr, const unsigned long long* __restrict__ blkK = nullptr) {
+    // blkA != nullptr (len == BLK == 512, log_e - k_first >= 4): the stages with pair distance <= 8 run on the matrix cores
     using E = typename F::elem;
     using TE = typename F::telem;
     static_assert(sizeof(E) == 32, "32-byte fields");
@@ -1060,7 +1095,10 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
         return act ? a[tid ^ h] : x;
     };
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
-    for (uint32_t k = k_first; k < k_inner; ++k) {
+    bool mfma = false;
+    if constexpr (BLK == 512) mfma = blkA != nullptr;
+    const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;
+    for (uint32_t k = k_first; k < k_dec_end; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const bool hi = (tid >> lh) & 1u;
         const uint32_t off = (uint32_t)(e - 2 * (size_t)h) + (tid & (h - 1));
@@ -1071,7 +1109,12 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
             x = F::tmul_add(t, F::sub(B, A), lane_sel<F>(hi, F::zero(), A));   // lo: a + c0t*(b - a)   hi: dinv*(b - a)
         }
     }
-    if (log_e > 0 && k_first <= k_inner) {                                  // merged innermost stage pair (h = 1)
+    if constexpr (BLK == 512) {
+        if (mfma) {                                                         // len == BLK: every thread holds an element
+            x = Blk16::phase512_regs(a, x, blkA, blkK, tid);
+        }
+    }
+    if (log_e > 0 && k_first <= k_inner && !mfma) {                         // merged innermost stage pair (h = 1)
         const bool hi = tid & 1u;
         TE t; if (act) t = ldt(inner, hi ? 1u : 0u);
         const E xp = partner(1);
@@ -1080,7 +1123,7 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
             x = F::tmul_add(t, F::sub(B, A), A);
         }
     }
-    for (uint32_t k = k_inner; k-- > k_first;) {
+    for (uint32_t k = k_dec_end; k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         const bool hi = (tid >> lh) & 1u;
         const uint32_t off = (uint32_t)(e - 2 * (size_t)h) + (tid & (h - 1));
@@ -1104,9 +1147,15 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
+    // matrix-core form of the stages with pair distance <= 8 (mfma_blk16.h): arrays of 512 (one element per thread) or of whole
+    // 1024-element sub-tiles, vectors of >= 16 elements
+    const uint8_t* bA = nullptr; const unsigned long long* bK = nullptr;
+    if constexpr (sizeof(E) == 32 && BLK == 512) {
+        if (log_e >= 4 && (len == 512u || (len & 1023u) == 0)) { bA = T.blk16_A[srcpar]; bK = T.blk16_K[srcpar]; }
+    }
     if constexpr (sizeof(E) == 32 && ECFFT_REG_ENGINE) {
         if (len <= (uint32_t)BLK && (len & 63u) == 0) {
-            reg_extend32<F, BLK>(a, len, log_e, 0, T.c0t[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], tid);
+            reg_extend32<F, BLK>(a, len, log_e, 0, T.c0t[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], tid, len == (uint32_t)BLK ? bA : nullptr, bK);
             return;
         }
     }
@@ -1155,12 +1204,28 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
         if (len == BLK * 8) { lds_extend_fast<F, 8, BLK>(a, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], e, log_e, tid); return; }
     }
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
-    for (uint32_t k = 0; k < k_inner; ++k) {
+    bool mfma = false;
+    if constexpr (sizeof(E) == 32 && BLK == 512) mfma = bA != nullptr && (len & 1023u) == 0;
+    const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;
+    for (uint32_t k = 0; k < k_dec_end; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, true, BLK>(a, T.np0[srcpar] + (e - 2 * (size_t)h), T.dinv[srcpar] + (e - 2 * (size_t)h), lh, npairs, tid, T.c0t[srcpar] + (e - 2 * (size_t)h));
         __syncthreads();
     }
-    if (log_e > 0) {                                    // merged innermost stage pair (h = 1)
+    if constexpr (sizeof(E) == 32 && BLK == 512) {
+        if (mfma) {
+            Blk16::APre pre = Blk16::prefetch(bA, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            Blk16::to_operand_form<BLK>(a, len, tid);
+#pragma unroll 1
+            for (uint32_t o = 0; o < len; o += Blk16::kSub) {
+                if (o) { pre = Blk16::prefetch(bA, tid); __builtin_amdgcn_sched_barrier(0); }
+                Blk16::phase(a + o, bA, bK, tid, pre);
+            }
+            Blk16::from_swizzled<BLK>(a, len, tid);
+        }
+    }
+    if (log_e > 0 && !mfma) {                           // merged innermost stage pair (h = 1)
         const typename F::telem c0 = ldt(T.inner[srcpar], 0u), c1 = ldt(T.inner[srcpar], 1u);
         for (uint32_t g = tid; g < npairs; g += BLK) {
             E x = a[2 * g], y = a[2 * g + 1];
@@ -1170,7 +1235,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
         }
         __syncthreads();
     }
-    for (uint32_t k = k_inner; k-- > 0;) {
+    for (uint32_t k = k_dec_end; k-- > 0;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, BLK>(a, T.p0[tgt] + (e - 2 * (size_t)h), T.p1[tgt] + (e - 2 * (size_t)h), lh, npairs, tid);
         __syncthreads();

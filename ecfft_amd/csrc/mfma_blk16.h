@@ -28,6 +28,10 @@
 #include <stdint.h>
 #include "field_secp256k1.h"
 
+#ifndef BLK16_STAMP
+#define BLK16_STAMP(k)
+#endif
+
 namespace ecfft {
 
 struct Blk16 {
@@ -56,19 +60,28 @@ struct Blk16 {
     }
 
     // 32 signed column sums (digit b = lo[b] for b < 16, hi[b - 16] above) + the output's seeds K -> canonical residue
+    // KV = false: K is wave-uniform (scalar loads, SGPR operand); true: K differs per lane (vector loads)
+    template <bool KV = false>
     __device__ static __forceinline__ E normalise(const int (&lo)[16], const int (&hi)[16], const unsigned long long* __restrict__ K) {
         long long W[8];
         const uint32_t s8 = 1u << 8, s16 = 1u << 16, s24 = 1u << 24;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int* y = g < 4 ? &lo[4 * g] : &hi[4 * (g - 4)];
-            const unsigned long long kg = K[g];            // wave-uniform: scalar load
+            const unsigned long long kg = K[g];
             long long w;
-            asm("v_mad_i64_i32 %0, vcc, %1, 1, %5\n\t"
-                "v_mad_i64_i32 %0, vcc, %2, %6, %0\n\t"
-                "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\t"
-                "v_mad_i64_i32 %0, vcc, %4, %8, %0"
-                : "=&v"(w) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "s"(kg), "s"(s8), "s"(s16), "s"(s24) : "vcc");
+            if constexpr (KV)
+                asm("v_mad_i64_i32 %0, vcc, %1, 1, %5\n\t"
+                    "v_mad_i64_i32 %0, vcc, %2, %6, %0\n\t"
+                    "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\t"
+                    "v_mad_i64_i32 %0, vcc, %4, %8, %0"
+                    : "=&v"(w) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(kg), "s"(s8), "s"(s16), "s"(s24) : "vcc");
+            else
+                asm("v_mad_i64_i32 %0, vcc, %1, 1, %5\n\t"
+                    "v_mad_i64_i32 %0, vcc, %2, %6, %0\n\t"
+                    "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\t"
+                    "v_mad_i64_i32 %0, vcc, %4, %8, %0"
+                    : "=&v"(w) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "s"(kg), "s"(s8), "s"(s16), "s"(s24) : "vcc");
             W[g] = w;                                      // in [2^50 - 2^48, 2^50 + 2^48 + 2^32)
         }
         uint32_t z0 = (uint32_t)W[0], z1, z2, z3, z4, z5, z6, z7, z8, t, c8;
@@ -134,46 +147,59 @@ struct Blk16 {
         __syncthreads();
     }
 
-    // The map on the 64 blocks of one 1024-element sub-tile held in operand form; results are written back PLAIN (canonical
-    // residues in the ordinary element layout).  512 threads: wave w produces outputs o = 2w, 2w+1 of all 64 blocks — four
-    // 32 x 32 accumulators, so every data operand is read from LDS once per wave, and the operands of input i+1 (two constant
-    // matrices from L2, two data operands from LDS) are requested before the four MFMAs of input i issue.
-    // Ends with a barrier.
-    __device__ static __forceinline__ void phase(E* sub, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid) {
+    // one element -> operand form (bytes xor 0x80, swizzled chunks) at position j of an LDS array
+    __device__ static __forceinline__ void store_operand(E* arr, uint32_t j, const E& x) {
+        uint4* lds = reinterpret_cast<uint4*>(arr);
+        const uint32_t X = 0x80808080u;
+        lds[phys(j, 0)] = make_uint4(x.l[0] ^ X, x.l[1] ^ X, x.l[2] ^ X, x.l[3] ^ X);
+        lds[phys(j, 1)] = make_uint4(x.l[4] ^ X, x.l[5] ^ X, x.l[6] ^ X, x.l[7] ^ X);
+    }
+    // The constant matrices of inputs 0 and 1 for the wave's two outputs, requested EARLY (they do not depend on the data): the
+    // caller issues this before the sweep / barriers that produce the operand form, so the L2 latency of the first requests is
+    // hidden; follow the call with __builtin_amdgcn_sched_barrier(0) or the scheduler sinks the loads to their first use.
+    struct APre { v4i a[2][2]; };                           // [input][output]
+    typedef const __attribute__((address_space(1))) char* gchar;
+    typedef const __attribute__((address_space(1))) v4i* gv4;
+    __device__ static __forceinline__ gchar a_base(const uint8_t* __restrict__ Amat, uint32_t tid) {
+        const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        return (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(2 * w) * NB) * 1024 + L * 16;
+    }
+    __device__ static __forceinline__ v4i ldA(gchar ap, int oo, int i) { return *(gv4)(ap + ((size_t)oo * NB + (size_t)i) * 1024); }
+    __device__ static __forceinline__ APre prefetch(const uint8_t* __restrict__ Amat, uint32_t tid) {
+        const gchar ap = a_base(Amat, tid);
+        APre p; p.a[0][0] = ldA(ap, 0, 0); p.a[0][1] = ldA(ap, 1, 0); p.a[1][0] = ldA(ap, 0, 1); p.a[1][1] = ldA(ap, 1, 1);
+        return p;
+    }
+
+    // The map on the 64 blocks of one 1024-element sub-tile held in operand form; results are canonical residues (plain bytes)
+    // left at the SWIZZLED chunk positions (load_swizzled / from_swizzled).  512 threads: wave w produces outputs o = 2w, 2w+1 of all 64 blocks — four
+    // 32 x 32 accumulators, so every data operand is read from LDS once per wave; the constant matrices run two inputs ahead
+    // of the MFMAs (L2 latency), the data operands one.  Ends with a barrier.
+    __device__ static __forceinline__ void phase(E* sub, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid, const APre& pre) {
         uint4* lds = reinterpret_cast<uint4*>(sub);
         const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 31, h = L >> 5;
-        typedef const __attribute__((address_space(1))) char* gchar;
-        typedef const __attribute__((address_space(1))) v4i* gv4;
-        const gchar ap = (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(2 * w) * NB) * 1024 + L * 16;
-        auto ldA = [&](int oo, int i) { return *(gv4)(ap + ((size_t)oo * NB + (size_t)i) * 1024); };
+        const gchar ap = a_base(Amat, tid);
         // operand address of (block, input i): phys() reduces to a0 ^ 32*i bytes (2i | h never carries), batch 1 is 16 KiB above
         const uint32_t a0 = 16u * phys(n * NB, h);
         const char* lb = reinterpret_cast<const char*>(lds);
         auto ldB = [&](int r, int i) { const uint4 b = *reinterpret_cast<const uint4*>(lb + ((a0 ^ (32u * (uint32_t)i)) + 16384u * (uint32_t)r)); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
         v16i acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};           // acc[output][batch]
-        v4i A0 = ldA(0, 0), A1 = ldA(1, 0), B0 = ldB(0, 0), B1 = ldB(1, 0);
+        v4i A0 = pre.a[0][0], A1 = pre.a[0][1], A0b = pre.a[1][0], A1b = pre.a[1][1];
+        BLK16_STAMP(1)
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            v4i nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
-#if defined(BLK16_EXP) && BLK16_EXP == 1      // experiment: no constant-matrix traffic
-            if (i + 1 < NB) { nB0 = ldB(0, i + 1); nB1 = ldB(1, i + 1); }
-#elif defined(BLK16_EXP) && BLK16_EXP == 3    // experiment: no LDS operand traffic
-            if (i + 1 < NB) { nA0 = ldA(0, i + 1); nA1 = ldA(1, i + 1); }
-#else
-            if (i + 1 < NB) { nA0 = ldA(0, i + 1); nA1 = ldA(1, i + 1); nB0 = ldB(0, i + 1); nB1 = ldB(1, i + 1); }
-#endif
+            v4i nA0 = A0b, nA1 = A1b;
+            if (i + 2 < NB) { nA0 = ldA(ap, 0, i + 2); nA1 = ldA(ap, 1, i + 2); }
+            const v4i B0 = ldB(0, i), B1 = ldB(1, i);   // LDS latency is covered by the SIMD's other wave; 128 VGPRs leave no room to run ahead
             __builtin_amdgcn_sched_barrier(0);          // keep the requests ABOVE the MFMAs (the scheduler sinks them to their uses)
-#if defined(BLK16_EXP) && BLK16_EXP == 2      // experiment: no MFMA
-            acc00[i] += A0[0] ^ B0[1]; acc01[i] += A0[1] ^ B1[2]; acc10[i] += A1[2] ^ B0[3]; acc11[i] += A1[3] ^ B1[0];
-#else
             acc00 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, acc00, 0, 0, 0);
             acc01 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B1, acc01, 0, 0, 0);
             acc10 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B0, acc10, 0, 0, 0);
             acc11 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B1, acc11, 0, 0, 0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-            A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+            A0 = A0b; A1 = A1b; A0b = nA0; A1b = nA1;
         }
+        BLK16_STAMP(2)
         E outz[2];
 #pragma unroll
         for (int oo = 0; oo < 2; ++oo) {
@@ -185,15 +211,91 @@ struct Blk16 {
             }
             outz[oo] = normalise(lo, hi, Kc + (2 * w + oo) * 8);
         }
+        BLK16_STAMP(3)
         __syncthreads();        // every operand read of this phase is done: the tile can be overwritten
+        BLK16_STAMP(4)
 #pragma unroll
         for (int oo = 0; oo < 2; ++oo) {
             const uint32_t j = L * NB + 2 * w + oo;           // lane L holds block L (batch L >> 5, column L & 31)
             const E& z = outz[oo];
-            lds[2 * j] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);
-            lds[2 * j + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7]);
+            // SWIZZLED chunk positions (plain bytes): a wave's 64 results are 512 B apart, one bank in the plain layout
+            lds[phys(j, 0)] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);
+            lds[phys(j, 1)] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7]);
         }
         __syncthreads();
+    }
+    // element j of an array whose chunks sit at their swizzled positions (what phase() leaves behind)
+    __device__ static __forceinline__ E load_swizzled(const E* arr, uint32_t j) {
+        const uint4* lds = reinterpret_cast<const uint4*>(arr);
+        const uint4 a = lds[phys(j, 0)], b = lds[phys(j, 1)];
+        E r; r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+        return r;
+    }
+    // swizzled chunk positions -> ordinary layout, T elements (a multiple of 512).  Ends with a barrier.
+    template <int BLK>
+    __device__ static __forceinline__ void from_swizzled(E* tile, uint32_t T, uint32_t tid) {
+#pragma unroll 1
+        for (uint32_t base = 0; base < T; base += 2 * BLK) {
+            const uint32_t j0 = base + tid, j1 = base + BLK + tid;
+            const bool two = j1 < T;
+            const E a = load_swizzled(tile, j0); E b = a;
+            if (two) b = load_swizzled(tile, j1);
+            __syncthreads();
+            tile[j0] = a; if (two) tile[j1] = b;
+        }
+        __syncthreads();
+    }
+
+    // The same map on a 512-element array (32 blocks: ONE batch, k_exit_low's half-tiles) whose element tid the calling thread
+    // holds in registers (x, plain).  Wave w produces outputs 2w and 2w+1 of the 32 blocks; the register swap pairs the two
+    // OUTPUTS instead of two batches: afterwards lanes 0..31 own output 2w of block lane, lanes 32..63 output 2w+1 of block
+    // lane - 32, and the accumulator seeds differ per lane half.  The constant matrices of the first four inputs are requested
+    // before the barrier that lets the array be overwritten (the tables of a low-level kernel's many trees are L2 misses as often
+    // as not).  Returns element tid of the result; ends with a barrier.
+    __device__ static __forceinline__ E phase512_regs(E* sub, const E& x, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid) {
+        uint4* lds = reinterpret_cast<uint4*>(sub);
+        const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 31, h = L >> 5;
+        const gchar ap = a_base(Amat, tid);
+        constexpr int D = 4;                                            // inputs in flight
+        v4i QA0[D], QA1[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { QA0[d] = ldA(ap, 0, d); QA1[d] = ldA(ap, 1, d); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                // readers of the array's previous contents are done
+        store_operand(sub, tid, x);
+        __syncthreads();
+        const uint32_t a0 = 16u * phys(n * NB, h);
+        const char* lb = reinterpret_cast<const char*>(lds);
+        auto ldB = [&](int i) { const uint4 b = *reinterpret_cast<const uint4*>(lb + (a0 ^ (32u * (uint32_t)i))); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
+        v16i acc0 = {0}, acc1 = {0};                                     // acc[output]
+        v4i B0 = ldB(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const v4i A0 = QA0[i % D], A1 = QA1[i % D];
+            v4i nB0 = B0;
+            if (i + D < NB) { QA0[i % D] = ldA(ap, 0, i + D); QA1[i % D] = ldA(ap, 1, i + D); }
+            if (i + 1 < NB) nB0 = ldB(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B0, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            B0 = nB0;
+        }
+        int lo[16], hi[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            auto p = __builtin_amdgcn_permlane32_swap((unsigned)acc0[r], (unsigned)acc1[r], false, false);
+            lo[r] = (int)p[0]; hi[r] = (int)p[1];
+        }
+        const E z = normalise<true>(lo, hi, Kc + (2 * w + h) * 8);
+        __syncthreads();        // every operand read of this phase is done
+        {
+            const uint32_t j = n * NB + 2 * w + h;
+            lds[phys(j, 0)] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);      // swizzled positions: see phase()
+            lds[phys(j, 1)] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7]);
+        }
+        __syncthreads();
+        return load_swizzled(sub, tid);
     }
 
     // ---- construction: the 16 x 16 matrix of the tree (the kernels' own stage code applied to the unit vectors), its

@@ -25,6 +25,10 @@
 using namespace ecfft;
 using F = Secp256k1;
 
+#ifdef STAMPS
+__device__ unsigned long long g_stamp[8][8];       // [wave][point]
+#define BLK16_STAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_stamp[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); }
+#endif
 #include "../../ecfft_amd/csrc/mfma_blk16.h"
 constexpr int NB = 16;            // points of the composite map
 constexpr int TILE = 1024;        // elements per workgroup tile (32 KiB of LDS)
@@ -41,7 +45,15 @@ __global__ __launch_bounds__(BLK, MINW) void k_block16(const Fe256* __restrict__
     for (uint32_t j = tid; j < TILE; j += BLK) tile[j] = in[base + j];
     __syncthreads();
 #pragma unroll 1
-    for (int r = 0; r < reps; ++r) { Blk16::to_operand_form<BLK>(tile, TILE, tid); Blk16::phase(tile, Amat, Kc, tid); }
+    for (int r = 0; r < reps; ++r) {
+#ifdef STAMPS
+        BLK16_STAMP(0)
+#endif
+        Blk16::APre pre = Blk16::prefetch(Amat, tid); __builtin_amdgcn_sched_barrier(0); Blk16::to_operand_form<BLK>(tile, TILE, tid); Blk16::phase(tile, Amat, Kc, tid, pre); Blk16::from_swizzled<BLK>(tile, TILE, tid);
+#ifdef STAMPS
+        BLK16_STAMP(5)
+#endif
+    }
     for (uint32_t j = tid; j < TILE; j += BLK) out[base + j] = tile[j];
 }
 
@@ -163,6 +175,14 @@ int main(int argc, char** argv) {
         printf("MFMA block-16 map, %d application(s): %zu / %zu outputs %s\n", check_reps, checked - bad, checked, bad ? "MISMATCH" : "bit-exact vs host");
     }
 
+#ifdef STAMPS
+    for (int tl : {1, 256, 512}) {
+        k_block16<<<tl, BLK>>>(din, dout, dA, dK, 3); (void)hipDeviceSynchronize();
+        unsigned long long st[8][8]; (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+        printf("stamps (shader cycles, block 0, last of 3 reps; grid %d): start -> A req + operand form -> MFMA loop -> swap+normalise -> barrier -> write+barrier\n", tl);
+        for (int w = 0; w < 8; ++w) printf("  wave %d: conv %6llu  mfma %6llu  norm %6llu  bar %6llu  write %6llu   total %6llu\n", w, st[w][1] - st[w][0], st[w][2] - st[w][1], st[w][3] - st[w][2], st[w][4] - st[w][3], st[w][5] - st[w][4], st[w][5] - st[w][0]);
+    }
+#endif
     // timing
     std::vector<Te256> htab(64);
     for (auto& t : htab) { t.t = rnd_elem(); t.u = F::mul(t.t, pow2(128)); }
