@@ -160,6 +160,8 @@ def main():
                     help="extend-split: BASELINE configs[3] — ONE EXTEND of 2^log-n evaluations split over the ranks with RCCL all-to-all; "
                          "enter-exit-split: ONE ENTER+EXIT of 2^log-n coefficients split over the ranks (strong scaling)")
     ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
+    ap.add_argument("--split-log-n", type=int, default=20, help="--gpus N > 1: size of the ONE ENTER+EXIT split over the ranks reported under `split` (0 = skip)")
+    ap.add_argument("--split-log-e", type=int, default=22, help="--gpus N > 1: size of the ONE EXTEND split over the ranks reported under `split` (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -186,10 +188,14 @@ def main():
             dist.init_process_group(backend)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    if args.mode == "extend-split":
-        return extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev)
-    if args.mode == "enter-exit-split":
-        return enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev)
+    if args.mode in ("extend-split", "enter-exit-split"):
+        fn = extend_split if args.mode == "extend-split" else enter_exit_split
+        line = fn(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.log_n)
+        if rank == 0:
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
@@ -269,6 +275,18 @@ def main():
                    "field_mul_per_s_per_gpu": (we_ + wx_) * B * args.steps / tb}
         del big, evb, backb
 
+    # ---- --gpus N > 1: besides the replica line, the north_star partitioning itself — ONE transform with its evaluation domain
+    # split over the ranks (grouped ncclSend/ncclRecv at the top log2 N levels, sharded tables), same process group ----------
+    split_obj = None
+    if world > 1 and (args.split_log_n or args.split_log_e):
+        del tree, coeffs, ev, back
+        torch.cuda.empty_cache()
+        split_obj = {"ranks": world, "transport": "rccl" if backend == "nccl" else f"callback over {backend} (functional test)"}
+        if args.split_log_n:
+            split_obj["enter_exit"] = enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_n)
+        if args.split_log_e:
+            split_obj["extend"] = extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_e)
+
     if rank == 0:
         we, wx = w_mul(n)
         value = (we + wx) * args.steps * world / elapsed
@@ -288,6 +306,8 @@ def main():
             "cpu_baseline": None,
             "batched": batched,
         }
+        if split_obj is not None:
+            out["split"] = split_obj              # N = 1 lines carry no such key (byte-compatible with earlier rounds)
         out.update(split)
         if world == 1 and args.cpu_log_n > 0:
             out["cpu_baseline"] = cpu_baseline(args.field, args.cpu_log_n)
@@ -314,12 +334,13 @@ def _split_report(comm, steps):
             "bytes_sent_per_step_per_rank": st["bytes_sent"] / max(steps, 1)}
 
 
-def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda"):
+def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda", log_e=None):
     """BASELINE configs[3]: one EXTEND of e = 2^log_n evaluations (tree T_2e) with the evaluation domain split over the
     ranks: block-distributed input, four grouped ncclSend/ncclRecv exchanges (block<->cyclic) around the top log2(P) stages,
     all below the C ABI (ecfft_extend_sharded).  Strong scaling: total work is fixed.  Checked by S0->S1->S0 round trip."""
     from ecfft_amd import distributed as D
-    e = 1 << args.log_n
+    log_e = args.log_n if log_e is None else log_e
+    e = 1 << log_e
     F = ecfft_amd.FIELDS[args.field]
     # sharded EXTEND-only context: this rank's 1/world share of the tables of T_2e, nothing else (ecfft_build_extend_shard)
     t_b = time.perf_counter()
@@ -331,6 +352,7 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     host = synth(args.field, e, 0x5EED0004)[rank * c:(rank + 1) * c]          # this rank's block of the same global vector
     x = torch.from_numpy(host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).cuda()
     comm = _make_comm(D, dist, world)
+    comm_world = comm.world
 
     def run(v, moiety):
         return tree.extend_sharded(comm, v, e, moiety)
@@ -364,32 +386,31 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
         fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
-    if rank == 0:
-        L = args.log_n
-        print(json.dumps({"metric": f"{args.field} Fp field-mul/s, one EXTEND of 2^{L} evaluations split over {world} GPU(s)",
-                          "value": 4 * e * L * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
-                          "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1} (BASELINE.json configs[3])", "e": e,
-                                     "parallelism": f"evaluation domain block-split over {world} GPU(s): ecfft_extend_sharded, 4 grouped ncclSend/ncclRecv exchanges per EXTEND",
-                                     "tables": "sharded: each GPU holds its 1/world share of T_2e's EXTEND tables (ecfft_build_extend_shard)",
-                                     "table_bytes_per_gpu": tree.device_bytes, "context_build_s": build_s},
-                          "phases": phases, "round_trip_ok": ok}))
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    L = log_e
+    return {"metric": f"{args.field} Fp field-mul/s, one EXTEND of 2^{L} evaluations split over {world} GPU(s)",
+            "value": 4 * e * L * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+            "config": {"workload": f"{args.field}::Fp EXTEND e=2^{L} on T_2^{L + 1}" + (" (BASELINE.json configs[3])" if L == 22 and args.field == "secp256k1" else ""), "e": e,
+                       "parallelism": f"evaluation domain block-split over {world} GPU(s): ecfft_extend_sharded, 4 grouped ncclSend/ncclRecv exchanges per EXTEND",
+                       "tables": "sharded: each GPU holds its 1/world share of T_2e's EXTEND tables (ecfft_build_extend_shard)",
+                       "table_bytes_per_gpu": tree.device_bytes, "context_build_s": build_s},
+            "phases": phases, "round_trip_ok": ok, "ranks_seen_by_transport": comm_world}
 
 
-def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda"):
+def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda", log_n=None):
     """ONE ENTER followed by ONE EXIT of n = 2^log_n coefficients with the evaluation domain block-split over the ranks
     (ecfft_amd/distributed.py: local low levels, split EXTENDs + table_fma + one all-to-all per top level).  Strong
     scaling.  Checked by EXIT(ENTER(c)) == c on every rank."""
     from ecfft_amd import distributed as D
-    n = 1 << args.log_n
+    log_n = args.log_n if log_n is None else log_n
+    n = 1 << log_n
     F = ecfft_amd.FIELDS[args.field]
     c = n // world
     host = synth(args.field, n, 0x5EED0005)[rank * c:(rank + 1) * c]
     x = torch.from_numpy((host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)).reshape(c, -1).copy()).cuda()
     comm = _make_comm(D, dist, world)
+    comm_world = comm.world
     t_b = time.perf_counter()
     if world > 1:
         # sharded contexts: the chain up to n/world + this rank's share of the top trees (the EXIT one is a collective build)
@@ -435,18 +456,33 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
         fl = torch.tensor([1 if ok else 0], device=red_dev); dist.all_reduce(fl, op=dist.ReduceOp.MIN); ok = bool(fl.item())
-    if rank == 0:
-        we, wx = w_mul(n)
-        print(json.dumps({"metric": f"{args.field} Fp field-mul/s, one ENTER+EXIT at n=2^{args.log_n} split over {world} GPU(s)",
-                          "value": (we + wx) * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
-                          "config": {"workload": f"{args.field}::Fp n=2^{args.log_n} ENTER+EXIT, one transform", "n": n,
-                                     "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s): ecfft_enter_sharded / ecfft_exit_sharded; levels above n/P use split EXTENDs and one re-blocking exchange per level",
-                                     "tables": tables, "table_bytes_per_gpu": table_bytes, "context_build_s": build_s},
-                          "phases": phases, "round_trip_ok": ok}))
-    if dist is not None:
-        dist.barrier(); dist.destroy_process_group()
+    we, wx = w_mul(n)
+    return {"metric": f"{args.field} Fp field-mul/s, one ENTER+EXIT at n=2^{log_n} split over {world} GPU(s)",
+            "value": (we + wx) * args.steps / elapsed, "unit": "field-mul/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u256" if args.field == "secp256k1" else "u32", "data": "synthetic",
+            "config": {"workload": f"{args.field}::Fp n=2^{log_n} ENTER+EXIT, one transform", "n": n,
+                       "parallelism": f"coefficient/evaluation vector block-split over {world} GPU(s): ecfft_enter_sharded / ecfft_exit_sharded; levels above n/P use split EXTENDs and one re-blocking exchange per level",
+                       "tables": tables, "table_bytes_per_gpu": table_bytes, "context_build_s": build_s},
+            "phases": phases, "round_trip_ok": ok, "ranks_seen_by_transport": comm_world}
+
+
+def kernel_source_hash():
+    """the hash tools/counters_json.py stamps into a counters file (same code, kept in one place there)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import counters_json
+        return counters_json.kernel_source_hash()
+    except Exception:  # pragma: no cover
+        return None
+    finally:
+        sys.path.pop(0)
+
+
+def compulsory_bytes(n, s):
+    """what ENTER+EXIT cannot avoid moving: each transform's input and output once (4 n s) and every table element
+    the pair needs once (ENTER u EXIT = 11 m per tree, 22 n for the chain)"""
+    return s * (4 * n + 22 * n)
 
 
 INSTR_PER_MUL = {"secp256k1": 169, "m31": 6}     # VALU instructions of the kernels' table multiply-add (tools/gen_mulmod_asm.py; field_m31.h)
@@ -510,8 +546,15 @@ def build_roofline(args, F, n, classes, step_s, device):
         per_class.append(row)
     drow = next(r for r in per_class if r["name"] == dom["name"])
     be, bx = b_alg(n, F.elem_bytes)
+    cur_hash = kernel_source_hash()
+    ctr_hash = (ctr or {}).get("kernel_source_hash")
+    stale = bool(ctr) and (ctr_hash is None or cur_hash is None or ctr_hash != cur_hash)
     out = {"kernel": dom["name"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "achieved": drow.get("hbm_counter_GBs"), "frac": drow.get("hbm_frac"), "traffic": drow.get("hbm_bytes_per_launch"),
+           # the SURVEY 8(d) formula, as the contract words it: ALGORITHMIC (stage-streaming) bytes of one launch of the dominant
+           # kernel / its live launch time / 8 TB/s.  NOT a utilisation (>= 10 stages share one HBM round trip): see `effective`
+           "achieved_alg": drow["effective_GBs"], "frac_alg": drow["effective_GBs"] / HBM_PEAK_GBS,
+           "counters_kernel_hash": ctr_hash, "running_kernel_hash": cur_hash, "counters_stale": stale,
            "launches_per_step": drow["launches_per_step"], "avg_launch_us": drow["avg_launch_us"],
            "share_of_event_time": dom["ms"] / max(sum(c["ms"] for c in live), 1e-12),
            "effective": {"GBs": drow["effective_GBs"], "alg_bytes_per_launch": drow["alg_bytes_per_launch"],
@@ -521,15 +564,22 @@ def build_roofline(args, F, n, classes, step_s, device):
                                  "round trip in the fused kernels, so this can exceed the HBM line and is not a fraction of it"},
            "per_class": per_class, "counters_source": src,
            "note": "achieved / frac / traffic: HBM bytes really moved per launch of the dominant kernel (rocprofv3 PMC, committed under "
-                   "profiles/) over its launch time measured in this run with HIP events"}
+                   "profiles/) over its launch time measured in this run with HIP events; achieved_alg / frac_alg: the same launch time under "
+                   "SURVEY 8(d)'s algorithmic bytes; counters_stale = the PMC pass was taken from other kernel sources than the ones running"}
     try:
         clock_mhz = F.shader_clock_mhz(device)
         ceil4, ceil8 = F.mul_ceiling(4, device), F.mul_ceiling(8, device)
         xe_, xx_ = executed_mul(n)
         out["clock_mhz_under_multiply_load"] = clock_mhz
-        out["valu"] = {"executed_mul_per_step": xe_ + xx_, "achieved": (xe_ + xx_) / step_s, "peak": max(ceil4, ceil8), "unit": "mul/s",
-                       "frac": (xe_ + xx_) / step_s / max(ceil4, ceil8), "peak_at_4_waves_per_simd": ceil4, "peak_at_8_waves_per_simd": ceil8,
-                       "note": "peak = ecfft_mul_ceiling: the kernels' table multiply as a bare dependent chain on the whole chip"}
+        tot_mfma = sum((cls_ctr.get(c["name"]) or {}).get("SQ_INSTS_VALU_MFMA_I8", 0.0) * c["launches"] / args.steps for c in live)
+        on_mfma = 14.0 * tot_mfma           # a 1024-element phase = 512 MFMAs in place of 7 sweeps x 1024 multiplies (mfma_blk16.h)
+        valu_mul = max(xe_ + xx_ - on_mfma, 0.0)
+        out["valu"] = {"executed_mul_per_step": xe_ + xx_, "of_which_on_matrix_cores": on_mfma, "valu_mul_per_step": valu_mul,
+                       "achieved": valu_mul / step_s, "peak": max(ceil4, ceil8), "unit": "mul/s",
+                       "frac": valu_mul / step_s / max(ceil4, ceil8), "peak_at_4_waves_per_simd": ceil4, "peak_at_max_occupancy": ceil8,
+                       "note": "peak = ecfft_mul_ceiling: the kernels' OWN 169-instruction table multiply as a bare dependent chain on the whole "
+                               "chip (8 workgroups per CU requested; the 94-VGPR chain fits 5 waves per SIMD) - a ceiling of this "
+                               "implementation's multiply, not of the machine: see valu_machine for the instruction-issue utilisation"}
         if tot_insts:
             ipm = INSTR_PER_MUL[args.field]
             floor = clock_mhz * 1e6 * N_SIMD * 64 / (max(ceil4, ceil8) * ipm)     # cycles per wave-instruction per SIMD of the bare chain
@@ -541,9 +591,28 @@ def build_roofline(args, F, n, classes, step_s, device):
                                          "tools/ubench/clock.hip)"}
     except Exception as ex:  # pragma: no cover
         out["valu"] = {"error": str(ex)}
+    # machine-level pipe utilisation from the SQ counters (independent of any multiply model): busy cycles of the VALU and of
+    # the matrix cores over step time x measured clock x 1024 SIMDs.  SQ_ACTIVE_INST_VALU counts 4-cycle quads, SQ_VALU_MFMA_BUSY_CYCLES cycles.
+    try:
+        clk = out.get("clock_mhz_under_multiply_load")
+        act = sum((cls_ctr.get(c["name"]) or {}).get("SQ_ACTIVE_INST_VALU", 0.0) * c["launches"] / args.steps for c in live)
+        mbusy = sum((cls_ctr.get(c["name"]) or {}).get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * c["launches"] / args.steps for c in live)
+        if clk and act:
+            simd_cycles = step_s * clk * 1e6 * N_SIMD
+            out["valu_machine"] = {"busy_frac": 4.0 * act / simd_cycles, "SQ_ACTIVE_INST_VALU_per_step": act,
+                                   "note": "4 x SQ_ACTIVE_INST_VALU (quad-cycles the VALU was issuing) / (step time x measured shader clock x 1024 SIMDs)"}
+            out["mfma"] = {"busy_frac": mbusy / simd_cycles, "SQ_VALU_MFMA_BUSY_CYCLES_per_step": mbusy,
+                           "instructions_per_step": sum((cls_ctr.get(c["name"]) or {}).get("SQ_INSTS_VALU_MFMA_I8", 0.0) * c["launches"] / args.steps for c in live),
+                           "note": "v_mfma_i32_32x32x32_i8 of the innermost 16-point maps (mfma_blk16.h); the matrix pipe is a side channel here, "
+                                   "the integer VALU still binds"}
+    except Exception:  # pragma: no cover
+        pass
+    comp = compulsory_bytes(n, F.elem_bytes)
+    out["compulsory"] = {"bytes_per_step": comp, "ms_at_peak": comp / (HBM_PEAK_GBS * 1e9) * 1e3,
+                         "note": "in + out of both transforms + every needed table element once (SURVEY 8(d)); the floor of any implementation"}
     if tot_bytes and complete:
         out["whole_job"] = {"hbm_counter_GBs": tot_bytes / step_s / 1e9, "hbm_frac": tot_bytes / step_s / 1e9 / HBM_PEAK_GBS,
-                            "hbm_bytes_per_step": tot_bytes}
+                            "hbm_bytes_per_step": tot_bytes, "traffic_over_compulsory": tot_bytes / comp}
     # what binds: the larger of the two measured fractions
     hb = (out.get("whole_job") or {}).get("hbm_frac") or out.get("frac") or 0.0
     vb = max((out.get("valu_issue") or {}).get("frac", 0.0), (out.get("valu") or {}).get("frac", 0.0))

@@ -1331,11 +1331,12 @@ public:
     // The reference's own (un-normalised) matrices of T_m, rebuilt on demand for export (src/fftree.rs:341-363):
     // R = [[v0, s0 v0], [v1, s1 v1]], v_j = v(s_j)^(d/2-1), D = R^-1; identity where d == 1.  out: 4*m elements on the
     // device, row-major Mat2x2 in BinaryTree heap order, crate representation.  Synchronous.
-    bool export_matrices(unsigned log_m, bool decompose, E* out, hipStream_t s) {
+    // standard = true: plain (standard-form) residues instead of the crate's in-memory form — what ark-serialize writes
+    bool export_matrices(unsigned log_m, bool decompose, E* out, hipStream_t s, bool standard = false) {
         size_t m = (size_t)1 << log_m, N = N_, stride = N_ / m;
         const E* f = f_; const E* den = den_;
         foreach_n(s, m, [=] __device__(size_t idx) {
-            E one = F::to_mont(F::one()), zero = F::zero();
+            E one = standard ? F::one() : F::to_mont(F::one()), zero = F::zero();
             E r00 = one, r01 = zero, r10 = zero, r11 = one;
             size_t d = 1; unsigned k = 0;
             if (idx >= 2) {                                   // layer k occupies [d, 2d), d = m >> (k+1)
@@ -1353,9 +1354,24 @@ public:
                     E di = F::inv(F::sub(F::mul(a, dd), F::mul(b, c)));
                     r00 = F::mul(dd, di); r01 = F::mul(F::neg(b), di); r10 = F::mul(F::neg(c), di); r11 = F::mul(a, di);
                 } else { r00 = a; r01 = b; r10 = c; r11 = dd; }
-                r00 = F::to_mont(r00); r01 = F::to_mont(r01); r10 = F::to_mont(r10); r11 = F::to_mont(r11);
+                if (!standard) { r00 = F::to_mont(r00); r01 = F::to_mont(r01); r10 = F::to_mont(r10); r11 = F::to_mont(r11); }
             }
             out[4 * idx] = r00; out[4 * idx + 1] = r01; out[4 * idx + 2] = r10; out[4 * idx + 3] = r11;
+        });
+        return hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+
+    // f of T_m (BinaryTree<F>, 2m entries, heap order; entry 0 unused = 0): every (N/m)-th element of each layer of the top
+    // tree's point set (src/fftree.rs:471-478), gathered on the device.  out: 2m elements on the device, plain.  Synchronous.
+    bool gather_f(unsigned log_m, E* out, hipStream_t s) const {
+        if (!f_) return false;
+        const size_t m = (size_t)1 << log_m, N = N_, stride = N_ / m;
+        const E* f = f_;
+        foreach_n(s, 2 * m, [=] __device__(size_t idx) {
+            if (idx == 0) { out[0] = F::zero(); return; }
+            const unsigned lg = 63 - __clzll((unsigned long long)idx);     // layer with 2^lg points: idx in [2^lg, 2^(lg+1))
+            const size_t sz = (size_t)1 << lg, j = idx - sz;
+            out[idx] = f[(N / m) * sz + j * stride];                       // that layer of the top tree has N*sz/m points
         });
         return hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }

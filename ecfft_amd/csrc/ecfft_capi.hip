@@ -137,8 +137,9 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
     return ECFFT_OK;
 }
 
+// standard = true: plain standard-form residues (the FFTree wire format) instead of the crate's in-memory representation
 template <class F>
-int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap, size_t* count) {
+int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap, size_t* count, bool standard = false) {
     using E = typename F::elem;
     if (!is_pow2(m)) return ECFFT_ERR_NOT_POW2;
     if (m > ch.size()) return ECFFT_ERR_TREE_TOO_SMALL;
@@ -166,26 +167,25 @@ int table_of(DeviceChain<F>& ch, size_t m, int which, void* host_out, size_t cap
         std::lock_guard<std::mutex> guard(ch.lock());
         void* d = nullptr;
         if (hipMalloc(&d, cnt * sizeof(E)) != hipSuccess) return ECFFT_ERR_HIP;
-        bool ok = ch.export_matrices(l, which == ECFFT_TBL_DECOMPOSE, (E*)d, nullptr) &&
+        bool ok = ch.export_matrices(l, which == ECFFT_TBL_DECOMPOSE, (E*)d, nullptr, standard) &&
                   hipMemcpy(o, d, cnt * sizeof(E), hipMemcpyDeviceToHost) == hipSuccess;
         (void)hipFree(d);
         return ok ? ECFFT_OK : ECFFT_ERR_HIP;      // already in the crate representation
     }
     if (which == ECFFT_TBL_F) {
-        // f of T_m: every (N/m)-th element of each layer of the top tree (src/fftree.rs:471-478)
-        // the point set lives on the device (computed there for build_fftree contexts)
-        size_t N = ch.size(), stride = N / m;
-        std::vector<E> f(2 * N);
-        if (!ch.f_device() || hipMemcpy(f.data(), ch.f_device(), 2 * N * sizeof(E), hipMemcpyDeviceToHost) != hipSuccess) return ECFFT_ERR_HIP;
-        o[0] = F::zero();
-        for (size_t sz = m, top = N; sz >= 1; sz >>= 1, top >>= 1) {
-            for (size_t j = 0; j < sz; ++j) o[sz + j] = f[top + j * stride];
-            if (sz == 1) break;
-        }
+        // f of T_m: every (N/m)-th element of each layer of the top tree (src/fftree.rs:471-478), gathered on the device — only
+        // the 2m entries asked for cross the bus
+        std::lock_guard<std::mutex> guard(ch.lock());
+        void* d = nullptr;
+        if (hipMalloc(&d, cnt * sizeof(E)) != hipSuccess) return ECFFT_ERR_HIP;
+        bool ok = ch.gather_f(l, (E*)d, nullptr) && hipMemcpy(o, d, cnt * sizeof(E), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        if (!ok) return ECFFT_ERR_HIP;
     } else if (cnt) {
         if (!src) return ECFFT_ERR_BAD_ARG;
         if (hipMemcpy(o, src, cnt * sizeof(E), hipMemcpyDeviceToHost) != hipSuccess) return ECFFT_ERR_HIP;
     }
+    if (standard) return ECFFT_OK;
     if constexpr (std::is_same<F, Secp256k1>::value) secp_to_mont_host(o, cnt);
     return ECFFT_OK;
 }
@@ -474,6 +474,190 @@ int run_sharded(ecfft_ctx* c, DeviceChain<F>& ch, ecfft_comm* comm, Op op, const
         case OP_EXIT: ok = ch.api_exit_split(tr, (const E*)in, (E*)out, len, s); break;
     }
     return ok && hipGetLastError() == hipSuccess ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+}  // namespace
+
+// ---- FFTree wire format (ark-serialize 0.4 conventions; hand-written impls at /root/reference/src/fftree.rs:510-660) ----------
+// Vec<T> = u64 little-endian length + elements; a field element = its STANDARD-form integer, little endian (32 / 4 bytes);
+// [T; N] = elements only; bool = one byte; DensePolynomial = coefficient Vec with trailing zeros trimmed.  Field order of one
+// tree (:528-548): f, recombine_matrices, decompose_matrices, rational_maps, xnn_s, z0_s1, z1_s0, [xnn_s_inv, z0_inv_s1,
+// z1_inv_s0 with Compress::No only], z0z0_rem_xnn_s, z1z1_rem_xnn_s, bool has_subtree, then the subtree.
+// The device tables are plain residues, so every table goes to the file as it lies in HBM.
+namespace {
+template <class F>
+size_t trimmed_len(const typename F::elem* c3) {
+    size_t k = 3;
+    while (k > 0 && F::is_zero(c3[k - 1])) --k;
+    return k;
+}
+template <class F>
+size_t wire_size(const DeviceChain<F>& ch, int compress) {
+    const size_t eb = sizeof(typename F::elem);
+    size_t total = 0;
+    for (size_t m = ch.size();; m >>= 1) {
+        const unsigned lm = ilog2(m); const size_t e = m / 2;
+        total += 8 + 2 * m * eb + 2 * (8 + 4 * m * eb) + 8;
+        for (unsigned k = 0; k < lm; ++k) total += 16 + (trimmed_len<F>(ch.host().maps[k].num) + trimmed_len<F>(ch.host().maps[k].den)) * eb;
+        total += ((8 + m * eb) + 2 * (8 + e * eb)) * (compress ? 1 : 2);
+        total += 2 * (8 + (m > 1 ? m : 0) * eb) + 1;
+        if (m == 1) break;
+    }
+    return total;
+}
+inline void put_u64(uint8_t*& p, uint64_t v) { for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(v >> (8 * i)); }
+template <class F>
+int wire_write(DeviceChain<F>& ch, int compress, uint8_t* buf) {
+    using E = typename F::elem;
+    const size_t eb = sizeof(E);
+    uint8_t* p = buf;
+    auto vec = [&](size_t m, int which, size_t per_entry) -> int {      // Vec of cnt / per_entry entries
+        size_t cnt = 0;
+        int rc = table_of(ch, m, which, nullptr, 0, &cnt, true);
+        if (rc != ECFFT_OK) return rc;
+        put_u64(p, cnt / per_entry);
+        if (cnt) { rc = table_of(ch, m, which, p, cnt, nullptr, true); if (rc != ECFFT_OK) return rc; }
+        p += cnt * eb;
+        return ECFFT_OK;
+    };
+    for (size_t m = ch.size();; m >>= 1) {
+        const unsigned lm = ilog2(m);
+        int rc;
+        if ((rc = vec(m, ECFFT_TBL_F, 1)) || (rc = vec(m, ECFFT_TBL_RECOMBINE, 4)) || (rc = vec(m, ECFFT_TBL_DECOMPOSE, 4))) return rc;
+        put_u64(p, lm);                                                   // the subtree keeps the first log2(m) maps (split_last, :480)
+        for (unsigned k = 0; k < lm; ++k) {
+            const RatMap<F>& mp = ch.host().maps[k];
+            const size_t ln = trimmed_len<F>(mp.num), ld = trimmed_len<F>(mp.den);
+            put_u64(p, ln); memcpy(p, mp.num, ln * eb); p += ln * eb;
+            put_u64(p, ld); memcpy(p, mp.den, ld * eb); p += ld * eb;
+        }
+        if ((rc = vec(m, ECFFT_TBL_XNN_S, 1)) || (rc = vec(m, ECFFT_TBL_Z0_S1, 1)) || (rc = vec(m, ECFFT_TBL_Z1_S0, 1))) return rc;
+        if (!compress && ((rc = vec(m, ECFFT_TBL_XNN_S_INV, 1)) || (rc = vec(m, ECFFT_TBL_Z0_INV_S1, 1)) || (rc = vec(m, ECFFT_TBL_Z1_INV_S0, 1)))) return rc;
+        if ((rc = vec(m, ECFFT_TBL_Z0Z0_REM_XNN_S, 1)) || (rc = vec(m, ECFFT_TBL_Z1Z1_REM_XNN_S, 1))) return rc;
+        *p++ = m > 1 ? 1 : 0;
+        if (m == 1) break;
+    }
+    return ECFFT_OK;
+}
+
+// cursor over the file: every read is bounds-checked (a truncated or corrupt file is ECFFT_ERR_BAD_ARG, never a wild read)
+struct WireIn {
+    const uint8_t* p; size_t left; bool bad = false;
+    bool u64(uint64_t* v) {
+        if (left < 8) { bad = true; return false; }
+        uint64_t r = 0; for (int i = 0; i < 8; ++i) r |= (uint64_t)p[i] << (8 * i);
+        p += 8; left -= 8; *v = r; return true;
+    }
+    const uint8_t* bytes(size_t n) {
+        if (left < n) { bad = true; return nullptr; }
+        const uint8_t* r = p; p += n; left -= n; return r;
+    }
+};
+template <class F>
+bool canonical_elems(const uint8_t* p, size_t cnt) {          // every element < p (ark-serialize rejects non-canonical encodings)
+    for (size_t i = 0; i < cnt; ++i) {
+        if constexpr (std::is_same<F, Secp256k1>::value) {
+            Fe256 v; memcpy(&v, p + 32 * i, 32);
+            bool lt = false;
+            for (int w = 7; w >= 0; --w) { const uint32_t pl = Secp256k1::p_limb(w); if (v.l[w] != pl) { lt = v.l[w] < pl; break; } }
+            if (!lt) return false;
+        } else {
+            uint32_t v; memcpy(&v, p + 4 * i, 4);
+            if (v >= 0x7FFFFFFFu) return false;
+        }
+    }
+    return true;
+}
+// one level of a parsed file: pointers into the file for every table (standard form), in ECFFT_TBL_* order
+struct WireLevel { size_t n = 0; const uint8_t* tbl[11] = {}; size_t cnt[11] = {}; };
+
+template <class F>
+int wire_read(int field, const uint8_t* data, size_t len, int compress, int device, int verify, ecfft_ctx** out,
+              std::unique_ptr<DeviceChain<F>> ecfft_ctx::*slot) {
+    using E = typename F::elem;
+    const size_t eb = sizeof(E);
+    WireIn in{data, len};
+    std::vector<WireLevel> levels;
+    HostTree<F> ht;
+    for (size_t expect = 0;; expect >>= 1) {
+        WireLevel lv;
+        auto vec = [&](int which, size_t per_entry, size_t want_entries, bool check_len) -> bool {
+            uint64_t n_ent = 0;
+            if (!in.u64(&n_ent)) return false;
+            if (check_len && n_ent != want_entries) { in.bad = true; return false; }
+            if (n_ent > in.left / (per_entry * eb)) { in.bad = true; return false; }
+            const uint8_t* q = in.bytes((size_t)n_ent * per_entry * eb);
+            if (!q || !canonical_elems<F>(q, (size_t)n_ent * per_entry)) { in.bad = true; return false; }
+            lv.tbl[which] = q; lv.cnt[which] = (size_t)n_ent * per_entry;
+            return true;
+        };
+        if (!vec(ECFFT_TBL_F, 1, 0, false)) return ECFFT_ERR_BAD_ARG;
+        const size_t two_m = lv.cnt[ECFFT_TBL_F];
+        if (two_m < 2 || (two_m & (two_m - 1))) return two_m >= 2 ? ECFFT_ERR_NOT_POW2 : ECFFT_ERR_BAD_ARG;
+        const size_t m = two_m / 2;
+        if (levels.empty()) expect = m; else if (m != expect) return ECFFT_ERR_BAD_ARG;
+        lv.n = m;
+        const unsigned lm = ilog2(m);
+        if (!vec(ECFFT_TBL_RECOMBINE, 4, m, true) || !vec(ECFFT_TBL_DECOMPOSE, 4, m, true)) return ECFFT_ERR_BAD_ARG;
+        uint64_t nmaps = 0;
+        if (!in.u64(&nmaps) || nmaps != lm) return ECFFT_ERR_BAD_ARG;
+        for (unsigned k = 0; k < lm; ++k) {
+            RatMap<F> mp;
+            for (int side = 0; side < 2; ++side) {
+                uint64_t nc = 0;
+                if (!in.u64(&nc) || nc > 3) return ECFFT_ERR_BAD_ARG;
+                const uint8_t* q = in.bytes((size_t)nc * eb);
+                if (!q || !canonical_elems<F>(q, (size_t)nc)) return ECFFT_ERR_BAD_ARG;
+                E* dst = side ? mp.den : mp.num;
+                for (int i = 0; i < 3; ++i) dst[i] = F::zero();
+                memcpy(dst, q, (size_t)nc * eb);
+            }
+            if (!F::is_zero(mp.den[2])) return ECFFT_ERR_BAD_ARG;          // x-map denominators have degree 1
+            if (levels.empty()) ht.maps.push_back(mp);
+            else if (memcmp(&ht.maps[k], &mp, sizeof(mp)) != 0) return ECFFT_ERR_BAD_ARG;   // a subtree keeps its parent's first maps
+        }
+        const size_t e = m / 2, zz = m > 1 ? m : 0;
+        if (!vec(ECFFT_TBL_XNN_S, 1, m, true) || !vec(ECFFT_TBL_Z0_S1, 1, e, true) || !vec(ECFFT_TBL_Z1_S0, 1, e, true)) return ECFFT_ERR_BAD_ARG;
+        if (!compress && (!vec(ECFFT_TBL_XNN_S_INV, 1, m, true) || !vec(ECFFT_TBL_Z0_INV_S1, 1, e, true) || !vec(ECFFT_TBL_Z1_INV_S0, 1, e, true))) return ECFFT_ERR_BAD_ARG;
+        if (!vec(ECFFT_TBL_Z0Z0_REM_XNN_S, 1, zz, true) || !vec(ECFFT_TBL_Z1Z1_REM_XNN_S, 1, zz, true)) return ECFFT_ERR_BAD_ARG;
+        const uint8_t* hs = in.bytes(1);
+        if (!hs || *hs > 1) return ECFFT_ERR_BAD_ARG;
+        levels.push_back(lv);
+        if (!*hs) { if (m != 1) return ECFFT_ERR_BAD_ARG; break; }
+        if (m == 1) return ECFFT_ERR_BAD_ARG;
+    }
+    if (in.left != 0) return ECFFT_ERR_BAD_ARG;                            // trailing bytes
+    // FFTree::new on the file's leaves and maps: every other table is recomputed on the GPU (the reference USES the file's
+    // tables; with verify != 0 each of them is compared with the recomputed one, so a file whose tables disagree with its own
+    // point set is rejected instead of being silently repaired).  Compress::Yes files carry no inverse tables (:620-628).
+    const size_t n = levels[0].n;
+    ht.n = n; ht.f.assign(2 * n, F::zero());
+    memcpy(ht.f.data() + n, levels[0].tbl[ECFFT_TBL_F] + n * eb, n * eb);
+    ht.leaves_only = true;
+    std::unique_ptr<ecfft_ctx> c(new (std::nothrow) ecfft_ctx());
+    if (!c) return ECFFT_ERR_HIP;
+    c->field = field; c->device = device;
+    int rc = guarded([&] { return finish_build(std::move(ht), device, (*c).*slot); });
+    if (rc != ECFFT_OK) return rc;
+    if (verify) {
+        DeviceGuard dev(device);
+        if (!dev.ok) return ECFFT_ERR_HIP;
+        DeviceChain<F>& ch = *((*c).*slot);
+        std::vector<E> got;
+        for (const WireLevel& lv : levels)
+            for (int which = 0; which < 11; ++which) {
+                if (!lv.tbl[which] && lv.cnt[which] == 0) continue;
+                got.resize(lv.cnt[which] ? lv.cnt[which] : 1);
+                rc = guarded([&] { return table_of(ch, lv.n, which, got.data(), lv.cnt[which], nullptr, true); });
+                if (rc != ECFFT_OK) return rc;
+                const size_t skip = which == ECFFT_TBL_F ? 1 : 0;           // heap index 0 is unused (src/utils.rs:228-252)
+                if (lv.cnt[which] > skip && memcmp((const uint8_t*)got.data() + skip * eb, lv.tbl[which] + skip * eb, (lv.cnt[which] - skip) * eb) != 0) {
+                    fprintf(stderr, "ecfft: table %d of the %zu-leaf subtree in the file differs from the one rebuilt from its point set\n", which, lv.n);
+                    return ECFFT_ERR_BAD_ARG;
+                }
+            }
+    }
+    *out = c.release();
+    return ECFFT_OK;
 }
 }  // namespace
 
@@ -839,6 +1023,49 @@ int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t
     if (ms_total) *ms_total = p.ms(cls);
     if (alg_bytes_total) *alg_bytes_total = p.bytes(cls);
     return ECFFT_OK;
+}
+
+int ecfft_tree_rational_maps(ecfft_ctx* ctx, void* map_num3_out, void* map_den3_out) {
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
+    if (ctx->field == ECFFT_FIELD_SECP256K1) {
+        const auto& maps = ctx->secp->host().maps;
+        for (size_t k = 0; k < maps.size(); ++k) {
+            RatMap<Secp256k1> m = maps[k];
+            secp_to_mont_host(m.num, 3); secp_to_mont_host(m.den, 3);
+            if (map_num3_out) memcpy((char*)map_num3_out + 96 * k, m.num, 96);
+            if (map_den3_out) memcpy((char*)map_den3_out + 96 * k, m.den, 96);
+        }
+    } else {
+        const auto& maps = ctx->m31->host().maps;
+        for (size_t k = 0; k < maps.size(); ++k) {
+            if (map_num3_out) memcpy((char*)map_num3_out + 12 * k, maps[k].num, 12);
+            if (map_den3_out) memcpy((char*)map_den3_out + 12 * k, maps[k].den, 12);
+        }
+    }
+    return ECFFT_OK;
+}
+
+int ecfft_fftree_serialize(ecfft_ctx* ctx, int compress, void* buf, size_t cap, size_t* len) {
+    if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
+    const size_t need = ctx->field == ECFFT_FIELD_SECP256K1 ? wire_size(*ctx->secp, compress) : wire_size(*ctx->m31, compress);
+    if (len) *len = need;
+    if (!buf) return ECFFT_OK;
+    if (cap < need) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(ctx->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? wire_write(*ctx->secp, compress, (uint8_t*)buf)
+                                                                    : wire_write(*ctx->m31, compress, (uint8_t*)buf); });
+}
+
+int ecfft_fftree_deserialize(int field, const void* bytes, size_t len, int compress, int device, int verify, ecfft_ctx** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (!bytes) return ECFFT_ERR_BAD_ARG;
+    if (field != ECFFT_FIELD_SECP256K1 && field != ECFFT_FIELD_M31) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    return guarded([&] { return field == ECFFT_FIELD_SECP256K1
+        ? wire_read<Secp256k1>(field, (const uint8_t*)bytes, len, compress, device, verify, out, &ecfft_ctx::secp)
+        : wire_read<M31>(field, (const uint8_t*)bytes, len, compress, device, verify, out, &ecfft_ctx::m31); });
 }
 
 int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n) {

@@ -30,7 +30,8 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z", "ecfft_build_exit_shard"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z", "ecfft_build_exit_shard",
+           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -108,6 +109,9 @@ def lib():
         L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
         L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+        L.ecfft_fftree_serialize.restype, L.ecfft_fftree_serialize.argtypes = ci, [vp, ci, vp, sz, ctypes.POINTER(sz)]
+        L.ecfft_fftree_deserialize.restype, L.ecfft_fftree_deserialize.argtypes = ci, [ci, vp, sz, ci, ci, ci, ctypes.POINTER(vp)]
+        L.ecfft_tree_rational_maps.restype, L.ecfft_tree_rational_maps.argtypes = ci, [vp, vp, vp]
         L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
         L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
@@ -233,6 +237,19 @@ class Field:
         h = ctypes.c_void_p()
         _check(lib().ecfft_fftree_new(self.id, leaves.ctypes.data, n, map_num.ctypes.data, map_den.ctypes.data, device, ctypes.byref(h)))
         return FFTree(self, h, device, maps=(map_num, map_den))
+
+
+def deserialize_fftree(field, data, compress, device=0, verify=True):
+    """`FFTree::deserialize_compressed / deserialize_uncompressed` (src/fftree.rs:600-660) through the C ABI
+    (ecfft_fftree_deserialize: bounds-checked parse, rebuild on the GPU, optional table-by-table verification)"""
+    data = bytes(data)
+    h = ctypes.c_void_p()
+    rc = lib().ecfft_fftree_deserialize(field.id, data, len(data), int(bool(compress)), device, int(bool(verify)), ctypes.byref(h))
+    if rc == ERR_BAD_ARG:
+        raise ValueError("malformed FFTree file (or its tables disagree with its point set)")
+    _check(rc)
+    t = FFTree(field, h, device)
+    return t
 
 
 secp256k1 = Field("secp256k1", 0, np.uint64, 4)
@@ -423,10 +440,20 @@ class FFTree:
         m = self.n if m is None else m
         return self.table(TBL_F, m)[m:]
 
+    def serialize(self, compress):
+        """`FFTree::serialize_compressed` (compress=True) / `serialize_uncompressed` (src/fftree.rs:510-554) through the C ABI"""
+        ln = ctypes.c_size_t()
+        _check(lib().ecfft_fftree_serialize(self._h, int(bool(compress)), None, 0, ctypes.byref(ln)))
+        buf = ctypes.create_string_buffer(ln.value)
+        _check(lib().ecfft_fftree_serialize(self._h, int(bool(compress)), buf, ln.value, ctypes.byref(ln)))
+        return buf.raw[:ln.value]
+
     def rational_map(self, k):
         """rational_maps[k] (src/fftree.rs:28) as (numerator[3], denominator[3]) coefficients, low -> high, zero padded"""
         if not hasattr(self, "_maps"):
-            _, num, den = self.field.build_points(self.n) if self._from_build else (None, self._num, self._den)
+            ln = max(self.n.bit_length() - 1, 1)
+            num = np.zeros(self.field.shape(3 * ln), self.field.dtype); den = np.zeros(self.field.shape(3 * ln), self.field.dtype)
+            _check(lib().ecfft_tree_rational_maps(self._h, num.ctypes.data, den.ctypes.data))
             self._maps = (num, den)
         num, den = self._maps
         return num[3 * k:3 * k + 3], den[3 * k:3 * k + 3]

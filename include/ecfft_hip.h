@@ -10,6 +10,7 @@
  *   ecfft_exit                    <-> FFTree::exit(&self, &[F]) -> Vec<F>                      src/fftree.rs:227-230
  *   ecfft_extend                  <-> FFTree::extend(&self, &[F], Moiety) -> Vec<F>            src/fftree.rs:123-126
  *   ecfft_tree_size / _table      <-> the pub fields of FFTree<F> / subtree_with_size          src/fftree.rs:24-38, 489-496
+ *   ecfft_fftree_serialize / _deserialize <-> impl CanonicalSerialize / CanonicalDeserialize  src/fftree.rs:507-660
  *   ecfft_ctx_destroy             <-> Drop
  *
  * Element representation = the crate's in-memory one, so Rust slices pass through untouched:
@@ -189,6 +190,22 @@ int ecfft_table_fma(ecfft_ctx* ctx, void* out, const void* x, const void* y, siz
 /* copy one table of the subtree with m leaves into host memory (element representation above);
  * returns the number of elements through *count; cap = capacity of host_out in elements. */
 int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t cap, size_t* count);
+
+/* FFTree wire format — impl CanonicalSerialize / CanonicalDeserialize for FFTree<F>, src/fftree.rs:507-660 (ark-serialize 0.4:
+ * Vec = u64 LE length + elements, field element = standard-form integer LE, bool = 1 byte).  `compress` != 0 is
+ * Compress::Yes: the three inverse tables are left out (:536-541) and regenerated on load (:620-628).
+ *   ecfft_fftree_serialize   <-> FFTree::serialize_compressed / serialize_uncompressed + serialized_size (:556-590): *len receives
+ *       the byte count; buf == NULL only asks for it; cap < *len is ECFFT_ERR_BAD_ARG.  Tables are copied out of HBM as they lie
+ *       there (plain residues = the standard form).
+ *   ecfft_fftree_deserialize <-> FFTree::deserialize_compressed / deserialize_uncompressed (:600-660): bounds-checked parse (a
+ *       truncated, non-canonical or inconsistent file is ECFFT_ERR_BAD_ARG), then FFTree::new on the file's leaves and maps —
+ *       every other table is recomputed on the GPU.  verify != 0 compares each table of the file with the recomputed one and
+ *       rejects the file on a mismatch (the reference trusts the file: Valid::check is a no-op, :592-597). */
+int ecfft_fftree_serialize(ecfft_ctx* ctx, int compress, void* buf, size_t cap, size_t* len);
+/* the pub field rational_maps (src/fftree.rs:28) of the top tree: log2(n) maps, 3 numerator + 3 denominator coefficients each
+ * (low -> high, zero padded), element representation as everywhere; either output may be NULL */
+int ecfft_tree_rational_maps(ecfft_ctx* ctx, void* map_num3_out, void* map_den3_out);
+int ecfft_fftree_deserialize(int field, const void* bytes, size_t len, int compress, int device, int verify, ecfft_ctx** out);
 
 /* Host-only front end of build_fftree (src/lib.rs:66-81) + the layer fill of FFTree::new
  * (src/fftree.rs:49-67): writes f (2n elements, heap order: f[n..2n) = leaves x(coset_offset + i*G))

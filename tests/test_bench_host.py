@@ -52,6 +52,13 @@ def test_roofline_uses_committed_counters_and_never_exceeds_one():
     assert all(0.0 < f <= 1.0 for f in fracs), fracs
     assert r["traffic"] == pytest.approx(r["achieved"] * 1e9 * r["avg_launch_us"] * 1e-6, rel=1e-6)      # achieved = traffic / launch time
     assert "frac" not in r["effective"]                                   # the stage-streaming figure is not a fraction
+    # round 3: both fractions are emitted under their own names; the algorithmic one may exceed 1 and says so in the note
+    assert r["frac_alg"] == pytest.approx(r["achieved_alg"] / bench.HBM_PEAK_GBS) and r["achieved_alg"] == pytest.approx(r["effective"]["GBs"])
+    assert r["compulsory"]["bytes_per_step"] == 32 * 26 * (1 << 20) and r["whole_job"]["traffic_over_compulsory"] > 1.0
+    assert isinstance(r["counters_stale"], bool) and r["running_kernel_hash"] == bench.kernel_source_hash()
+    assert 0.0 < r["valu_machine"]["busy_frac"] <= 1.0 and 0.0 <= r["mfma"]["busy_frac"] < 1.0
+    assert r["valu"]["of_which_on_matrix_cores"] + r["valu"]["valu_mul_per_step"] == pytest.approx(r["valu"]["executed_mul_per_step"])
+    assert "peak_at_8_waves_per_simd" not in r["valu"]
     json.dumps(r)
 
 
@@ -67,3 +74,41 @@ def test_cpu_quota_parsing(tmp_path, monkeypatch):
     q = bench._cpu_quota()
     assert q is None or q > 0
     assert bench._socket_cores() >= 1
+
+
+@pytest.mark.gpu
+def test_gpus2_line_carries_the_split_object():
+    """`--gpus N > 1` (the driver's SCALE command) prints the replica line AND, under `split`, ONE ENTER+EXIT and ONE EXTEND with
+    the evaluation domain split over the ranks.  Two ranks share this box's GPU through the gloo callback
+    transport (RCCL refuses two ranks on one device); on an N-GPU node the same command runs over RCCL / xGMI."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ECFFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "12",
+           "--split-log-n", "12", "--split-log-e", "12", "--cpu-log-n", "0", "--batch", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roofline"] is not None
+    sp = d["split"]
+    assert sp["ranks"] == 2
+    for key, exch in (("enter_exit", 1), ("extend", 4)):
+        o = sp[key]
+        assert o["round_trip_ok"] is True and o["scaling"] == "strong" and o["n_gpus"] == 2 and o["ranks_seen_by_transport"] == 2
+        ph = o["phases"]
+        assert ph["exchanges_per_step"] >= exch and ph["bytes_sent_per_step_per_rank"] > 0 and ph["comm_ms_per_step"] >= 0
+        assert "sharded" in o["config"]["tables"]
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_is_unchanged_by_the_split_option():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "12", "--cpu-log-n", "0", "--batch", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "split" not in d and d["n_gpus"] == 1 and d["roofline"]["frac_alg"] > 0

@@ -41,10 +41,45 @@ def test_deserialized_tree_works(oracle_tree, field, compress):
     P = ecfft_amd.FIELDS[field]
     F, ot = oracle_tree(field, 64)
     data = S.serialize_fftree(ot, P, compress)
-    t = S.deserialize_fftree(P, data, compress, verify=True)
+    t = S.deserialize_fftree(P, data, compress, verify=True)        # C ABI: ecfft_fftree_deserialize
     rng = np.random.default_rng(3)
     c = F.from_ints([int(x) for x in rng.integers(0, 2**31 - 1, 64)])
     assert np.array_equal(t.enter(c), ot.enter(c))
-    assert S.serialize_fftree(t, P, compress) == data
+    assert S.serialize_fftree(t, P, compress) == data                 # Python writer over the exported tables
+    assert S.serialize_device_tree(t, compress) == data               # C ABI: ecfft_fftree_serialize
     built = P.build_fftree(64)
     assert S.serialize_fftree(built, P, compress) == data
+    assert built.serialize(compress) == data
+    assert len(built.serialize(compress)) == S.serialized_size(P, 64, compress)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", FIELDS)
+def test_c_deserializer_rejects_bad_files(oracle_tree, field):
+    """the C parser is bounds-checked and validating: truncated files, trailing bytes, non-canonical elements, wrong vector
+    lengths and (verify) tables that disagree with the file's own point set are all refused, none of them crashes"""
+    import ecfft_amd
+    from ecfft_amd import serialize as S
+    P = ecfft_amd.FIELDS[field]
+    F, ot = oracle_tree(field, 16)
+    data = S.serialize_fftree(ot, P, False)
+    assert S.deserialize_fftree(P, data, False).n == 16
+    for bad in (data[:-1], data[:100], data + b"\x00", b"", data[:8]):
+        with pytest.raises(ValueError):
+            S.deserialize_fftree(P, bad, False)
+    eb = P.elem_bytes
+    noncanon = bytearray(data); noncanon[8 + 17 * eb: 8 + 18 * eb] = b"\xff" * eb        # leaf 1 = 2^k - 1 >= p
+    with pytest.raises(ValueError):
+        S.deserialize_fftree(P, bytes(noncanon), False)
+    wronglen = bytearray(data); wronglen[0:8] = (64).to_bytes(8, "little")                # f claims 64 entries
+    with pytest.raises(ValueError):
+        S.deserialize_fftree(P, bytes(wronglen), False)
+    # flip one byte inside xnn_s of the top tree: parses, but differs from the table rebuilt from the point set
+    off = 8 + 32 * eb + 2 * (8 + 64 * eb) + 8 + 4 * (16 + 5 * eb) + 8
+    tampered = bytearray(data); tampered[off] ^= 1
+    with pytest.raises(ValueError):
+        S.deserialize_fftree(P, bytes(tampered), False, verify=True)
+    assert S.deserialize_fftree(P, bytes(tampered), False, verify=False).n == 16     # the reference trusts the file too (Valid::check is a no-op)
+    # compressed files carry no inverse tables; the loaded tree has them (regenerated, src/fftree.rs:620-628)
+    t = S.deserialize_fftree(P, S.serialize_fftree(ot, P, True), True)
+    assert np.array_equal(t.table(S.T_XNN_S_INV, 16), ot.table(S.T_XNN_S_INV, 16))

@@ -7,10 +7,25 @@ streams of a transform) and average counters per launch (PMC passes; rocprofv3 s
 is the SOLO duration).  FETCH_SIZE / WRITE_SIZE are in KiB; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — the factor 2
 is the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-byte requests at 64 bytes)."""
 import glob
+import hashlib
 import json
 import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from: bench.py compares it with the running tree and flags a
+    counters file taken from other kernels as stale"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ecfft_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".inc")) and f not in ("host_curve.h", "transport.h"):      # device code + launch logic
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 CLASSES = {"k_stages_lds": ["k_stages_lds<"], "k_stages_col": ["k_stages_col<", "k_stages_col_mid<", "k_stages_col_enter<"],
            "k_enter_low": ["k_enter_low<"], "k_exit_low": ["k_exit_low<"], "k_decompose_stage": ["k_decompose_stage<"],
@@ -27,7 +42,8 @@ def klass(name):
 def main():
     out, field, log_n, reps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     launches = json.load(open(os.path.join(out, "launches.json")))
-    res = {"workload": f"{field} n=2^{log_n} ENTER+EXIT (tools/prof_case.py {field} {log_n} both {reps})", "reps": reps, "classes": {}}
+    res = {"workload": f"{field} n=2^{log_n} ENTER+EXIT (tools/prof_case.py {field} {log_n} both {reps})", "reps": reps,
+           "kernel_source_hash": kernel_source_hash(), "classes": {}}
     db = sqlite3.connect(os.path.join(out, "trace", "t_results.db"))
     by = {}
     for name, st, en in db.execute("select name, start, end from kernels order by start"):
