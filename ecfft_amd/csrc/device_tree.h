@@ -170,7 +170,9 @@ public:
     // ------------------------------------------------------------------------------------------
     // HBM held by this context between calls: table arena + transform scratch (pooled temporaries of the algorithm wrappers
     // and the host-call staging buffer come and go)
-    size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E); }
+    size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E) + pool_bytes(); }
+    // ecfft_ctx_trim: give every idle pooled temporary back to the device (between calls; takes the context lock)
+    void trim() { std::lock_guard<std::mutex> g(mu_); temps_trim(0); }
     enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2, kShardExit = 3 };
     int shard_kind() const { return shard_kind_; }
     bool shard_mode() const { return shard_kind_ != kShardNone; }
@@ -1430,18 +1432,48 @@ private:
         size_t a = (n + 7) & ~(size_t)7;
         if (slab_ && slab_used_ + a <= slab_cap_) { E* q = slab_ + slab_used_; slab_used_ += a; return q; }
         // pooled individual allocations: finish_api() / build_tree() hand them back to the pool instead of freeing them,
-        // so repeated algorithm calls (ecfft_redc, ecfft_degree, ...) do not hipMalloc / hipFree every time
+        // so repeated algorithm calls (ecfft_redc, ecfft_degree, ...) do not hipMalloc / hipFree every time.  Best fit, but a
+        // request never takes a block more than 4x its size (or 64 KiB): the 16-byte accumulator of ecfft_degree used to grab
+        // a multi-GiB block and force a fresh allocation for the next large request.
         size_t bytes = (a ? a : 8) * sizeof(E);
+        const size_t cap_fit = bytes * 4 > ((size_t)64 << 10) ? bytes * 4 : ((size_t)64 << 10);
         int best = -1;
         for (size_t i = 0; i < pool_.size(); ++i)
-            if (!pool_[i].busy && pool_[i].bytes >= bytes && (best < 0 || pool_[i].bytes < pool_[(size_t)best].bytes)) best = (int)i;
-        if (best >= 0) { pool_[(size_t)best].busy = true; return (E*)pool_[(size_t)best].p; }
+            if (!pool_[i].busy && pool_[i].bytes >= bytes && pool_[i].bytes <= cap_fit && (best < 0 || pool_[i].bytes < pool_[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0) { pool_[(size_t)best].busy = true; pool_[(size_t)best].idle_calls = 0; return (E*)pool_[(size_t)best].p; }
         void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "ecfft: temporary allocation of %zu bytes failed\n", bytes); throw DeviceAllocError(); }
-        pool_.push_back({p, bytes, true});
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            temps_trim(0);                                    // give back every idle pooled block and try once more
+            if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "ecfft: temporary allocation of %zu bytes failed\n", bytes); throw DeviceAllocError(); }
+        }
+        pool_.push_back({p, bytes, true, false, 0});
         return (E*)p;
     }
-    void temps_done() { for (auto& b : pool_) b.busy = false; }
+    // End of a call: every pooled temporary becomes reusable.  The pool is bounded: idle blocks beyond `keep` bytes in total
+    // (twice the transform scratch, at least 256 MiB) are returned to the device, largest first — one large ecfft_vanish /
+    // ecfft_degree no longer pins 6-10 n elements of HBM for the life of the context (ecfft_ctx_trim returns all of it).  Pinned blocks (the temporaries of a sharded transform whose shape the ranks have agreed on) are never trimmed.
+    void temps_done() {
+        for (auto& b : pool_) { if (!b.busy) ++b.idle_calls; b.busy = false; }
+        size_t keep = 2 * scratch_cap_ * sizeof(E);
+        if (keep < ((size_t)256 << 20)) keep = (size_t)256 << 20;
+        temps_trim(keep);                                    // rare: hipFree waits for the device
+    }
+    size_t pool_bytes() const { size_t t = 0; for (const auto& b : pool_) t += b.bytes; return t; }
+    // frees idle, unpinned blocks: those idle for > max_idle calls, then the largest ones until the idle total is <= keep bytes
+    void temps_trim(size_t keep, unsigned max_idle = ~0u) {
+        for (size_t i = 0; i < pool_.size();) {
+            if (!pool_[i].busy && !pool_[i].pinned && pool_[i].idle_calls > max_idle) { (void)hipFree(pool_[i].p); pool_[i] = pool_.back(); pool_.pop_back(); }
+            else ++i;
+        }
+        for (;;) {
+            size_t idle = 0; int big = -1;
+            for (size_t i = 0; i < pool_.size(); ++i)
+                if (!pool_[i].busy && !pool_[i].pinned) { idle += pool_[i].bytes; if (big < 0 || pool_[i].bytes > pool_[(size_t)big].bytes) big = (int)i; }
+            if (idle <= keep || big < 0) break;
+            (void)hipFree(pool_[(size_t)big].p); pool_[(size_t)big] = pool_.back(); pool_.pop_back();
+        }
+    }
     void temps_free() { for (auto& b : pool_) (void)hipFree(b.p); pool_.clear(); }
     void release() {
         temps_free();
@@ -1475,20 +1507,43 @@ private:
     }
 
     // ---- construction-time device primitives (plain data) ----
-    // out[i] = 1/in[i]; chunks of 8 share one Fermat inversion (Montgomery's trick).  Zero entries stay zero and do not
-    // disturb their neighbours, like ark_ff::batch_inversion (used at src/fftree.rs:235, 331-333, 409-414).
-    void batch_inv(const E* in, E* out, size_t n, hipStream_t s) {
-        constexpr size_t CH = 8;
-        size_t nth = (n + CH - 1) / CH;
-        foreach_n(s, nth, [=] __device__(size_t t) {
-            size_t b = t * CH, cnt = (b + CH <= n) ? CH : n - b;
-            E pre[CH], v[CH];
+    // out[i] = 1/in[i]; chunks share one Fermat inversion (Montgomery's trick).  Zero entries stay zero and do not disturb
+    // their neighbours, like ark_ff::batch_inversion (used at src/fftree.rs:235, 331-333, 409-414).  The inversion is a
+    // dependent chain of ~270 multiplies, i.e. its LATENCY is what a call costs; the chunk length grows with n so that at most
+    // one wave per SIMD runs such a chain (more waves would only share the issue slots and stretch every chain), and the
+    // prefix products live in `out` / a temporary instead of per-thread arrays (round 2: 528 B of scratch per thread).
+    // Several independent arrays in ONE launch (the inversion chain's latency is paid once, not once per table).
+    struct InvSeg { const E* in; E* out; size_t n; };
+    struct InvSegs { const E* in[6]; E* out[6]; E* pre[6]; size_t n[6], first[7]; int k; };
+    void batch_inv(const E* in, E* out, size_t n, hipStream_t s) { const InvSeg g{in, out, n}; batch_inv_multi(&g, 1, s); }
+    void batch_inv_multi(const InvSeg* segs, int k, hipStream_t s) {
+        size_t total = 0;
+        for (int j = 0; j < k; ++j) total += segs[j].n;
+        if (!total || k > 6) return;
+        size_t CH = 8;
+        while (CH < 64 && (total + CH - 1) / CH + (size_t)k > (size_t)65536) CH *= 2;
+        InvSegs g{}; g.k = 0; g.first[0] = 0;
+        for (int j = 0; j < k; ++j) {
+            if (!segs[j].n) continue;
+            const int q = g.k++;
+            g.in[q] = segs[j].in; g.out[q] = segs[j].out; g.n[q] = segs[j].n;
+            g.pre[q] = (segs[j].in == segs[j].out) ? temp(segs[j].n) : segs[j].out;   // in-place calls keep their inputs until the backward pass
+            g.first[q + 1] = g.first[q] + (segs[j].n + CH - 1) / CH;                  // chunks never straddle two arrays
+        }
+        foreach_n(s, g.first[g.k], [=] __device__(size_t t) {
+            int q = 0;
+            while (q + 1 < g.k && t >= g.first[q + 1]) ++q;
+            const E* in = g.in[q]; E* out = g.out[q]; E* pre = g.pre[q];
+            const size_t n = g.n[q], b = (t - g.first[q]) * CH, cnt = (b + CH <= n) ? CH : n - b;
             E acc = F::one();
-            for (size_t i = 0; i < cnt; ++i) { v[i] = in[b + i]; pre[i] = acc; if (!F::is_zero(v[i])) acc = F::mul(acc, v[i]); }
+            for (size_t i = 0; i < cnt; ++i) { const E v = in[b + i]; pre[b + i] = acc; if (!F::is_zero(v)) acc = F::mul(acc, v); }
             acc = F::inv(acc);
             for (size_t i = cnt; i-- > 0;) {
-                if (F::is_zero(v[i])) { out[b + i] = F::zero(); continue; }
-                out[b + i] = F::mul(acc, pre[i]); acc = F::mul(acc, v[i]);
+                const E v = in[b + i];
+                if (F::is_zero(v)) { out[b + i] = F::zero(); continue; }
+                const E r = F::mul(acc, pre[b + i]);
+                acc = F::mul(acc, v);
+                out[b + i] = r;
             }
         });
     }
@@ -1584,7 +1639,7 @@ private:
         {
             E* xnn = T.xnn; uint64_t ex = m / 2;
             foreach_n(s, m, [=] __device__(size_t j) { xnn[j] = F::pow_u64(f[N + j * stride], ex); });
-            batch_inv(T.xnn, T.xnn_inv, m, s);
+            if (l == 0) batch_inv(T.xnn, T.xnn_inv, m, s);      // otherwise inverted together with the stage tables below
         }
         if (l == 0) return true;
         unsigned le = ilog2(e);
@@ -1608,7 +1663,6 @@ private:
                     E b = f[lay + (2 * i + sg + 2 * h) * stride];
                     p0[g] = a; p1[g] = b; np0[g] = F::neg(a); dinv[g] = F::sub(b, a);
                 });
-                batch_inv(dinv, dinv, e - 1, s);
             }
             // normalisation weights W(s) of the leaves of parity sg (DESIGN.md "Normalised butterflies")
             E* w = hw[sg]; const E* den = den_;
@@ -1624,7 +1678,13 @@ private:
                 }
                 w[i] = U;
             });
-            batch_inv(hw[sg], hwinv[sg], e, s);
+        }
+        E *xq = nullptr, *xqi = nullptr;                        // X^(m/4) on the leaves of T_m and its inverse (src/fftree.rs:328-330), used below
+        if (l >= 2) { xq = temp(m); xqi = temp(m); E* q = xq; uint64_t ex = m / 4; foreach_n(s, m, [=] __device__(size_t j) { q[j] = F::pow_u64(f[N + j * stride], ex); }); }
+        {   // 1/xnn_s, 1/(s1 - s0) and 1/W of both parities, 1/X^(m/4): six independent arrays, ONE inversion launch
+            const InvSeg segs[6] = {{T.xnn, T.xnn_inv, m}, {hdinv[0], hdinv[0], e - 1}, {hdinv[1], hdinv[1], e - 1}, {hw[0], hwinv[0], e}, {hw[1], hwinv[1], e},
+                                    {xq, xqi, l >= 2 ? m : 0}};
+            batch_inv_multi(segs, 6, s);
         }
         // merged innermost stage pair (h = 1, stage k = le-1): out_j = a + c_j*(b - a) with
         // c_j = (p_j^target - p_0^source) / (p_1^source - p_0^source), table offset e-2 (kernels.h)
@@ -1687,8 +1747,7 @@ private:
             b_vanish(l, s1, van, s);
             { E* z1 = T.z1_s0; foreach_n(s, e, [=] __device__(size_t i) { z1[i] = van[2 * i]; }); }
         }
-        batch_inv(T.z0_s1, T.z0_inv_s1, e, s);
-        batch_inv(T.z1_s0, T.z1_inv_s0, e, s);
+        { const InvSeg segs[2] = {{T.z0_s1, T.z0_inv_s1, e}, {T.z1_s0, T.z1_inv_s0, e}}; batch_inv_multi(segs, 2, s); }
         if (l >= 2) {
             const Tree& S = trees_[l - 1];
             // a0inv / a1 views of xnn_s for REDC on this tree and on the subtree
@@ -1697,9 +1756,6 @@ private:
             E* sxa0i = temp(e / 2 ? e / 2 : 1); E* sxa1 = temp(e / 2 ? e / 2 : 1);
             { const E *xi = S.xnn_inv, *x = S.xnn; foreach_n(s, e / 2, [=] __device__(size_t i) { sxa0i[i] = xi[2 * i]; sxa1[i] = x[2 * i + 1]; }); }
             // X^(m/4) tables on the leaves of T_m (src/fftree.rs:328-330)
-            E* xq = temp(m); E* xqi = temp(m);
-            { uint64_t ex = m / 4; foreach_n(s, m, [=] __device__(size_t j) { xq[j] = F::pow_u64(f[N + j * stride], ex); }); }
-            batch_inv(xq, xqi, m, s);
             E* xqa0i = temp(e); E* xqa1 = temp(e);
             foreach_n(s, e, [=] __device__(size_t i) { xqa0i[i] = xqi[2 * i]; xqa1[i] = xq[2 * i + 1]; });
             // z0z0_rem_xnn_s (src/fftree.rs:418-446)
@@ -1763,7 +1819,7 @@ private:
     E* slab_ = nullptr; size_t slab_cap_ = 0, slab_used_ = 0;
     std::vector<Tree> trees_;
     Tree* d_trees_ = nullptr;
-    struct PoolBuf { void* p; size_t bytes; bool busy; };
+    struct PoolBuf { void* p; size_t bytes; bool busy; bool pinned; unsigned idle_calls; };
     std::vector<PoolBuf> pool_;
     std::mutex mu_;
     mutable Profiler prof_;

@@ -843,6 +843,14 @@ long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m) {
         return (int)(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->selfcheck_pointwise_z(m) : ctx->m31->selfcheck_pointwise_z(m));
     });
 }
+int ecfft_ctx_trim(ecfft_ctx* ctx) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    DeviceGuard dev(ctx->device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    if (ctx->field == ECFFT_FIELD_SECP256K1) ctx->secp->trim(); else ctx->m31->trim();
+    if (ctx->stage) { (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    return ECFFT_OK;
+}
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx) {
     if (!ctx) return 0;
     return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->device_bytes() : ctx->m31->device_bytes();

@@ -207,15 +207,20 @@ struct Secp256k1 {
         for (int i = 63; i >= 0; --i) { r = sqr(r); if ((e >> i) & 1) r = mul(r, a); }
         return r;
     }
-    // a^(p-2); p-2 = 2^256 - 2^32 - 979 = [0xFFFFFC2D, 0xFFFFFFFE, 0xFFFFFFFF x6]
+    __host__ __device__ static inline elem sqrn(elem a, int n) { for (int i = 0; i < n; ++i) a = sqr(a); return a; }
+    // a^(p-2), p-2 = 2^256 - 2^32 - 979 = 223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1 (binary): the addition chain that builds
+    // 2^k - 1 for k = 2, 3, 6, 9, 11, 22, 44, 88, 176, 220, 223 — 255 squarings + 15 multiplies instead of the 256 + 248 of
+    // square-and-multiply.  The chain is a dependent sequence, so its LENGTH is the latency of every batched inversion of the
+    // construction (device_tree.h batch_inv: one inversion per chunk, all chunks in parallel).
     __host__ __device__ static inline elem inv(const elem& a) {
-        elem r = one();
-        for (int i = 255; i >= 0; --i) {
-            r = sqr(r);
-            uint32_t wv = (i >= 64) ? 0xFFFFFFFFu : (i >= 32 ? 0xFFFFFFFEu : 0xFFFFFC2Du);
-            if ((wv >> (i & 31)) & 1) r = mul(r, a);
-        }
-        return r;
+        const elem x2 = mul(sqr(a), a), x3 = mul(sqr(x2), a);
+        const elem x6 = mul(sqrn(x3, 3), x3), x9 = mul(sqrn(x6, 3), x3), x11 = mul(sqrn(x9, 2), x2);
+        const elem x22 = mul(sqrn(x11, 11), x11), x44 = mul(sqrn(x22, 22), x22), x88 = mul(sqrn(x44, 44), x44);
+        const elem x176 = mul(sqrn(x88, 88), x88), x220 = mul(sqrn(x176, 44), x44), x223 = mul(sqrn(x220, 3), x3);
+        elem t = mul(sqrn(x223, 23), x22);
+        t = mul(sqrn(t, 5), a);
+        t = mul(sqrn(t, 3), x2);
+        return mul(sqrn(t, 2), a);
     }
     // a^((p+1)/4); (p+1)/4 = 2^254 - 2^30 - 244 -> words [0xBFFFFF0C, 0xFFFFFFFF x6, 0x3FFFFFFF]
     __host__ static inline bool sqrt(const elem& a, elem* out) {

@@ -135,7 +135,8 @@ def test_split_extend_building_blocks_on_one_gpu(oracle_mod, field, e, log_p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("m31", 1 << 20, 3), ("secp256k1", 1 << 8, 2)])
+@pytest.mark.parametrize("field,e,log_p", [("secp256k1", 1 << 12, 1), ("secp256k1", 1 << 13, 3), ("m31", 1 << 15, 2), ("m31", 1 << 20, 3), ("secp256k1", 1 << 8, 2),
+                                           ("secp256k1", 1 << 22, 3)])   # last: BASELINE configs[3] — e = 2^22 over P = 8, all four layouts
 def test_extend_shard_context_on_one_gpu(field, e, log_p):
     """ecfft_build_extend_shard: P sharded EXTEND-only contexts (each holding only its rank's table entries) driven as P
     ranks of one process — a callback transport whose exchange is a barrier + device-to-device copies between the ranks'
@@ -259,7 +260,8 @@ def _thread_ranks(P, body):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])   # last: chunk 2^20 runs the two-halves schedule
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2),    # chunk 2^20 runs the two-halves schedule
+                                       ("secp256k1", 1 << 20, 8)])   # last: the BASELINE metric's size (configs[2]) over P = 8
 def test_enter_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_enter_shard: P sharded ENTER-only contexts (chain up to n/P + the rank's share of the log2 P top trees) driven
     as the ranks of one process == the single-GPU ENTER of a full context, bit for bit; smaller HBM footprint; other calls refused"""
@@ -301,7 +303,8 @@ def test_enter_shard_context_on_one_gpu(field, n, P):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])   # last: chunk 2^20 runs the two-halves schedule
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2),    # chunk 2^20 runs the two-halves schedule
+                                       ("secp256k1", 1 << 20, 8)])   # last: the BASELINE metric's size (configs[2]) over P = 8
 def test_exit_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_exit_shard (collective, distributed build of z0z0_rem_xnn_s): P sharded EXIT-only contexts as the ranks of one
     process == the single-GPU EXIT of a full context on arbitrary evaluations, bit for bit; other calls refused"""

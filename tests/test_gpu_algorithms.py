@@ -114,3 +114,25 @@ def test_pointwise_vanishing_tables_match_the_reference_construction(field, n):
     while m <= n:
         assert FT.lib().ecfft_selfcheck_pointwise_z(tree._h, m) == 0, (field, m)
         m *= 2
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_temporary_pool_is_counted_bounded_and_trimmable(field):
+    """the algorithm wrappers' pooled temporaries are part of ecfft_ctx_device_bytes, a tiny request does not take a
+    huge block, and ecfft_ctx_trim gives the pool back"""
+    import ecfft_amd
+    F = ecfft_amd.FIELDS[field]
+    t = F.build_fftree(1 << 14)
+    base = t.device_bytes
+    rng = np.random.default_rng(1)
+    ev = t.enter(rng.integers(1, 1000, size=(1 << 14,) + ((4,) if field == "secp256k1" else ()), dtype=F.dtype))
+    dom = rng.integers(1, 1000, size=(1 << 13,) + ((4,) if field == "secp256k1" else ()), dtype=F.dtype)
+    r1 = t.vanish(dom); d1 = t.degree(ev)
+    grown = t.device_bytes
+    assert grown > base                                   # the pool is visible in the footprint
+    r2 = t.vanish(dom); d2 = t.degree(ev)
+    assert t.device_bytes == grown                        # steady state: the same blocks are reused, nothing new is allocated
+    assert np.array_equal(r1, r2) and d1 == d2
+    t.trim()
+    assert t.device_bytes == base
+    assert np.array_equal(t.vanish(dom), r1) and t.degree(ev) == d1       # and the wrappers still work after a trim
