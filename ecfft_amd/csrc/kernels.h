@@ -338,6 +338,9 @@ constexpr int kBlockLds = ECFFT_BLOCK_LDS;   // threads per workgroup of the LDS
 #define ECFFT_BLOCK_ROW ECFFT_BLOCK_LDS
 #endif
 constexpr int kBlockRow = ECFFT_BLOCK_ROW;   // ... of the row kernel (k_stages_lds)
+#ifndef ECFFT_ROW_PIPE
+#define ECFFT_ROW_PIPE 1                     // row-kernel sweeps request the next sweep's table constants before the barrier
+#endif
 #ifndef ECFFT_MIN_WAVES
 #define ECFFT_MIN_WAVES 4                    // waves per SIMD the register allocator must leave room for
 #endif
@@ -554,6 +557,35 @@ __device__ __forceinline__ void lds_extend_fast(typename F::elem* a, const typen
     __syncthreads();
 }
 
+__device__ __forceinline__ void lds_barrier();
+// Row-kernel sweeps of a 32-byte field, one pair per thread (tile = 2 * BLK elements), with the two table constants of the NEXT
+// sweep requested before the barrier that ends the current one (see col_stages_pipe).  Pair distances 2^lh_from .. 2^lh_to
+// (downwards for DEC, upwards otherwise), table entry e - 2h + (pair index mod h).  Ends with a barrier.
+template <class F, bool DEC>
+__device__ __forceinline__ void row_stages_pipe(typename F::elem* tile, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                                uint32_t e, int lh_from, int lh_to, uint32_t tid) {
+    using E = typename F::elem;
+    using TE = typename F::telem;
+    if (DEC ? lh_from < lh_to : lh_from > lh_to) return;
+    auto geom = [&](int lh, uint32_t& idx, uint32_t& ti) {
+        const uint32_t h = 1u << lh, i = tid & (h - 1);
+        idx = ((tid >> lh) << (lh + 1)) + i; ti = e - 2 * h + i;
+    };
+    uint32_t idx, ti;
+    geom(lh_from, idx, ti);
+    TE na = ldt(ta, ti), nb = ldt(tb, ti);
+#pragma unroll 1
+    for (int lh = lh_from; DEC ? lh >= lh_to : lh <= lh_to; lh += DEC ? -1 : 1) {
+        const TE t0 = na, t1 = nb;
+        const uint32_t lo = idx, up = idx + (1u << lh);
+        const E a = tile[lo], b = tile[up];
+        if (DEC) { const E q1 = F::tmul(t1, F::sub(b, a)); tile[lo] = F::tmul_add(t0, q1, a); tile[up] = q1; }
+        else { const E o0 = F::tmul_add(t0, b, a), o1 = F::tmul_add(t1, b, a); tile[lo] = o0; tile[up] = o1; }
+        if (lh != lh_to) { geom(lh + (DEC ? -1 : 1), idx, ti); na = ldt(ta, ti); nb = ldt(tb, ti); }
+        lds_barrier();
+    }
+}
+
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
 __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
                                                            const typename F::telem* __restrict__ np0,
@@ -603,6 +635,11 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;              // mfma: VALU sweeps only for pair distances >= 16
     // mfma with T == 1024 and a decompose sweep at distance 16 in this kernel: that sweep writes its results in operand form itself
     const bool fuse16 = mfma && T == (uint32_t)Blk16::kSub && k_first < k_dec_end;
+    bool pipe = false;                                                  // one pair per thread: constants one sweep ahead
+    if constexpr (sizeof(E) == 32 && ECFFT_ROW_PIPE) pipe = npairs == (uint32_t)kBlockRow && (e >> 31) == 0;
+    if (pipe) {
+        if constexpr (sizeof(E) == 32) row_stages_pipe<F, true>(tile, np0, dinv, (uint32_t)e, (int)(log_e - k_first) - 1, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), tid);
+    } else
     for (uint32_t k = k_first; k < k_dec_end - (fuse16 ? 1u : 0u); ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid, c0t ? c0t + (e - 2 * (size_t)h) : nullptr);
@@ -666,6 +703,9 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         }
         __syncthreads();
     }
+    if (pipe) {
+        if constexpr (sizeof(E) == 32) row_stages_pipe<F, false>(tile, p0, p1, (uint32_t)e, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), (int)(log_e - k_first) - 1, tid);
+    } else
     for (uint32_t k = k_dec_end - (fuse16 ? 1u : 0u); k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, kBlockRow>(tile, p0 + (e - 2 * (size_t)h), p1 + (e - 2 * (size_t)h), lh, npairs, tid);
@@ -774,6 +814,56 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
     }
 }
 
+// Workgroup barrier that publishes LDS writes only: __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)),
+// which would turn every table request issued ahead of the barrier into a wait AT the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef ECFFT_COL_PIPE
+#define ECFFT_COL_PIPE 1
+#endif
+// Column stages of a 32-byte field with the table constants ONE SWEEP AHEAD (round 3).  A column pass of a single transform is one
+// workgroup per CU, and every sweep used to be "request two 64-byte constants from HBM / L2 -> wait -> two multiplies ->
+// barrier": the top sweeps' constants are read once per launch, so their latency was paid R times in a row (48 % VALU-busy solo,
+// profiles/r03).  Here the constants of sweep s+1 (they depend only on the thread's index) are requested right after the
+// multiplies of sweep s, when the registers are free again, and fly across the LDS-only barrier and the next sweep's LDS reads.
+// One pair per thread is pipelined (pair index tid); further pairs of the thread (two vectors per workgroup) load theirs in
+// place as before.  Same arithmetic, same order: bit-identical.  Ends with a barrier.
+template <class F, bool DEC, int BLK>
+__device__ __forceinline__ void col_stages_pipe(typename F::elem* tile, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                                uint32_t R, uint32_t log_c, uint32_t log_hs, size_t c0, size_t e, uint32_t tid, uint32_t npairs) {
+    using E = typename F::elem;
+    using TE = typename F::telem;
+    const uint32_t C = 1u << log_c, RS = col_row_stride<E>(C);
+    auto geom = [&](uint32_t st, uint32_t g, uint32_t& lo, uint32_t& up, uint32_t& ti) {
+        const uint32_t sft = DEC ? R - 1 - st : st, d = 1u << sft;
+        const uint32_t cc = g & (C - 1), pr = g >> log_c;
+        const uint32_t r = ((pr >> sft) << (sft + 1)) | (pr & (d - 1));
+        ti = (uint32_t)(e - 2 * (((size_t)1 << log_hs) << sft)) + ((r & (d - 1)) << log_hs) + (uint32_t)c0 + cc;
+        lo = r * RS + cc; up = lo + d * RS;
+    };
+    uint32_t lo, up, ti;
+    geom(0, tid, lo, up, ti);
+    TE na = ldt(ta, ti), nb = ldt(tb, ti);
+#pragma unroll 1
+    for (uint32_t st = 0; st < R; ++st) {
+        const TE t0 = na, t1 = nb;
+        const uint32_t lo0 = lo, up0 = up;
+        {
+            const E a = tile[lo0], b = tile[up0];
+            if (DEC) { const E q1 = F::tmul(t1, F::sub(b, a)); tile[lo0] = F::tmul_add(t0, q1, a); tile[up0] = q1; }
+            else { const E o0 = F::tmul_add(t0, b, a), o1 = F::tmul_add(t1, b, a); tile[lo0] = o0; tile[up0] = o1; }
+        }
+        for (uint32_t g = tid + BLK; g < npairs; g += BLK) {
+            uint32_t l2, u2, i2; geom(st, g, l2, u2, i2);
+            const E a = tile[l2], b = tile[u2];
+            if (DEC) { const E q1 = F::tmul(ldt(tb, i2), F::sub(b, a)); tile[l2] = F::tmul_add(ldt(ta, i2), q1, a); tile[u2] = q1; }
+            else { const E o0 = F::tmul_add(ldt(ta, i2), b, a), o1 = F::tmul_add(ldt(tb, i2), b, a); tile[l2] = o0; tile[u2] = o1; }
+        }
+        if (st + 1 < R) { geom(st + 1, tid, lo, up, ti); na = ldt(ta, ti); nb = ldt(tb, ti); }
+        lds_barrier();
+    }
+}
+
 // The R stages of a column tile (2^R rows x C columns in LDS, row distance 2^s at stage k = kb - s; table entry
 // ((row mod 2^s) << log_hs) + c0 + column, table base e - 2*(hs << s)).  DECOMPOSE runs s = R-1 .. 0, recombine 0 .. R-1.
 // 4-byte fields with exactly 16 elements per thread use the register-resident radix steps (up to 3 stages per LDS round
@@ -813,6 +903,13 @@ __device__ __forceinline__ void col_stages(typename F::elem* tile, const typenam
         }
     }
     const size_t hs = (size_t)1 << log_hs;
+    if constexpr (sizeof(E) == 32 && ECFFT_COL_PIPE) {
+        const uint32_t npairs = (halves * T) >> 1;
+        if (npairs >= (uint32_t)kBlockLds && npairs % kBlockLds == 0 && (e >> 32) == 0) {     // at least one pair per thread (not the pair-split small tiles)
+            col_stages_pipe<F, DEC, kBlockLds>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, npairs);
+            return;
+        }
+    }
     for (uint32_t st = 0; st < R; ++st) {
         const uint32_t sft = DEC ? R - 1 - st : st;
         const size_t h = hs << sft;
