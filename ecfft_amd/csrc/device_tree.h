@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <set>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -527,25 +528,34 @@ public:
         const unsigned lc = ilog2(c);
         ECFFT_HIP_TRY(hipSetDevice(device_));
         hipStream_t s = nullptr;
-        size_t total = 64 + 3 * L_ + 4096;
-        for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
-        total += log_p * (shard_set_elems(hc) + 5 * c + 256);
-        ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
-        arena_cap_ = total; arena_used_ = 0;
-        E* fdev = nullptr;
-        if (!upload_points(fdev, s)) return false;
-        struct Free { E* p; DeviceChain* ch; ~Free() { (void)hipFree(p); ch->f_ = nullptr; ch->ovr_tree_ = nullptr; ch->ovr_set_ = nullptr; } } free_f{fdev, this};
-        f_ = fdev;                                               // build_tree reads f_
-        if (!ensure_scratch(c)) return false;
-        create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
-        trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
-        for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
-        E* lc_inv = take(L_);
-        {
-            std::vector<E> h(L_, F::one());
-            for (unsigned k = 0; k < L_; ++k) h[k] = F::inv(host_.maps[k].num[2]);
-            ECFFT_HIP_TRY(hipMemcpy(lc_inv, h.data(), L_ * sizeof(E), hipMemcpyHostToDevice));
-        }
+        E* fdev = nullptr; E* lc_inv = nullptr;
+        struct Free { E*& p; DeviceChain* ch; ~Free() { if (p) (void)hipFree(p); ch->f_ = nullptr; ch->ovr_tree_ = nullptr; ch->ovr_set_ = nullptr; } } free_f{fdev, this};
+        // everything up to the first exchange is LOCAL work that can fail on one rank only (allocations, the chain up to n/P):
+        // the ranks agree on its outcome before any of them enters the collective part
+        auto local_part = [&]() -> bool {
+            try {
+                size_t total = 64 + 3 * L_ + 4096;
+                for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
+                total += log_p * (shard_set_elems(hc) + 5 * c + 256);
+                ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
+                arena_cap_ = total; arena_used_ = 0;
+                if (!upload_points(fdev, s)) return false;
+                f_ = fdev;                                               // build_tree reads f_
+                if (!ensure_scratch(c)) return false;
+                create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
+                trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
+                for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
+                lc_inv = take(L_);
+                std::vector<E> h(L_, F::one());
+                for (unsigned k = 0; k < L_; ++k) h[k] = F::inv(host_.maps[k].num[2]);
+                ECFFT_HIP_TRY(hipMemcpy(lc_inv, h.data(), L_ * sizeof(E), hipMemcpyHostToDevice));
+                return !fail_next_collective_;
+            } catch (const DeviceAllocError&) { return false; }
+        };
+        bool local_ok = local_part();
+        fail_next_collective_ = false;
+        if (const char* fr = getenv("ECFFT_TEST_FAIL_BUILD_RANK")) { if ((unsigned)atoi(fr) == rank) local_ok = false; }   // test hook: this rank's local part "fails"
+        if (!tr.vote(local_ok, s)) { fprintf(stderr, "ecfft: sharded EXIT build: the local part failed on %s rank\n", local_ok ? "another" : "this"); return false; }
         shard_kind_ = kShardExit; shard_log_p_ = log_p; shard_rank_ = rank;      // extend_split must read the shares from here on
         const E* f = fdev; const size_t N = N_;
         bool ok = true;
@@ -556,7 +566,9 @@ public:
             const int base = (int)((rank / Q) * Q), a = (int)rank - base, g = a / (int)half, ap = a % (int)half, subbase = base + g * (int)half;
             // Every length-m/2 vector of the level is CYCLIC over the group: entry j of the rank = position j*Q + a (api_exit_split).
             // ---- permanent: the rank's share of T_m for the level's split EXTENDs + its pointwise entries, compact
-            if (!build_shard_set(lm, lq, (unsigned)a, fdev, s, -1)) return false;
+            bool lvl_ok = false;
+            try { lvl_ok = build_shard_set(lm, lq, (unsigned)a, fdev, s, -1); } catch (const DeviceAllocError&) { lvl_ok = false; }
+            if (!tr.vote(lvl_ok, s)) return false;                         // the level's exchanges follow: all ranks or none
             Tree& T = trees_[lm];
             E *xe = temp(hc), *xei = take(hc), *xo = take(hc), *zib = take(hc), *c0 = take(hc), *c1 = take(hc), *q0 = take(hc), *q1 = take(hc);
             { const uint64_t ex = m / 2; const size_t qq = Q, aa = (size_t)a;
@@ -632,6 +644,7 @@ public:
         }
         ok = ok && hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         temps_free();
+        ok = tr.vote(ok, s);                                                // every rank reports the same outcome
         if (!ok) { fprintf(stderr, "ecfft: sharded EXIT table build failed\n"); return false; }
         host_.f.clear(); host_.f.shrink_to_fit();
         ECFFT_HIP_TRY(hipMalloc(&d_trees_, (L_ + 1) * sizeof(Tree)));
@@ -983,10 +996,29 @@ public:
         }
         return hipGetLastError() == hipSuccess;
     }
+    // Local preparation of a collective call (its temporaries) + agreement across the ranks (Transport::vote) the FIRST time a
+    // call shape is seen on this context: a rank whose allocation failed must not leave its peers blocked in ncclRecv.  After
+    // an agreed first call the shape's temporaries are pinned in the pool, so later calls of that shape allocate nothing, cannot
+    // fail locally and stay asynchronous (no vote).  Every rank makes the same calls with the same sizes (the ABI's contract), so
+    // "first time" is the same moment on all of them.
+    template <class Alloc>
+    bool collective_prepare(Transport& tr, int op, size_t len, int variant, hipStream_t s, Alloc alloc) {
+        bool local_ok = true;
+        try { alloc(); } catch (const DeviceAllocError&) { local_ok = false; }
+        if (fail_next_collective_) { local_ok = false; fail_next_collective_ = false; }        // test hook
+        const uint64_t key = ((uint64_t)op << 60) | ((uint64_t)variant << 56) | ((uint64_t)(unsigned)tr.world << 48) | (uint64_t)len;
+        if (agreed_shapes_.count(key)) return local_ok;
+        if (!tr.vote(local_ok, s)) { temps_done(); return false; }
+        agreed_shapes_.insert(key);
+        for (auto& b : pool_) if (b.busy) b.pinned = true;
+        return true;
+    }
+    void test_fail_next_collective() { fail_next_collective_ = true; }
     bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s, bool cyc_in = false, bool cyc_out = false) {
         const size_t P = (size_t)tr.world, c = e / P;
         if (P & (P - 1)) return false;
-        E* A = temp(c); E* B = temp(c);
+        E *A = nullptr, *B = nullptr;
+        if (!collective_prepare(tr, 1, e, (cyc_in ? 1 : 0) | (cyc_out ? 2 : 0), s, [&] { A = temp(c); B = temp(c); })) return false;
         bool ok = extend_split(tr, 0, ilog2(P), in, out, e, target, s, A, B, cyc_in, cyc_out);
         temps_done();
         return ok;
@@ -1003,7 +1035,8 @@ public:
         const size_t P = (size_t)tr.world, c = n / P, cp = c / P;
         if ((P & (P - 1)) || c < 2 * P) return false;
         const bool sh = shard_mode();
-        E* cur = temp(c); E* ext = temp(c); E* U = temp(c); E* V = temp(c); E* A = temp(c); E* B = temp(c);
+        E *cur = nullptr, *ext = nullptr, *U = nullptr, *V = nullptr, *A = nullptr, *B = nullptr;
+        if (!collective_prepare(tr, 2, n, 0, s, [&] { cur = temp(c); ext = temp(c); U = temp(c); V = temp(c); A = temp(c); B = temp(c); })) return false;
         bool ok = enter(in, cur, c, 1, s);
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
             const size_t half = Q / 2, m = c * Q, e = m / 2;
@@ -1057,8 +1090,9 @@ public:
     bool api_exit_split(Transport& tr, const E* in, E* out, size_t n, hipStream_t s) {
         const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
         if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
-        E* cur = temp(c); E* e0 = temp(hc); E* e1 = temp(hc); E* t0 = temp(hc); E* h0 = temp(hc); E* h1 = temp(hc); E* A = temp(hc); E* B = temp(hc);
-        E* x0 = temp(hc); E* x1 = temp(hc);
+        E *cur = nullptr, *e0 = nullptr, *e1 = nullptr, *t0 = nullptr, *h0 = nullptr, *h1 = nullptr, *A = nullptr, *B = nullptr, *x0 = nullptr, *x1 = nullptr, *Rb = nullptr;
+        if (!collective_prepare(tr, 3, n, 0, s, [&] { cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
+                                                      x0 = temp(hc); x1 = temp(hc); Rb = temp(c); })) return false;
         bool ok = true;
         const bool sh = shard_mode();
         {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
@@ -1068,7 +1102,6 @@ public:
                 const size_t rp = t & (P - 1), tp = t >> lp;
                 S[rp * 2 * cpp + tp] = in[2 * t]; S[rp * 2 * cpp + cpp + tp] = in[2 * t + 1];
             });
-            E* Rb = temp(c);
             ok = exchange_group(tr, 0, P, S, Rb, 2 * cpp, s);
             foreach_n(s, hc, [=] __device__(size_t j) { const size_t r = j / cpp, tp = j - r * cpp; e0[j] = Rb[r * 2 * cpp + tp]; e1[j] = Rb[r * 2 * cpp + cpp + tp]; });
         }
@@ -1820,6 +1853,8 @@ private:
     std::vector<Tree> trees_;
     Tree* d_trees_ = nullptr;
     struct PoolBuf { void* p; size_t bytes; bool busy; bool pinned; unsigned idle_calls; };
+    std::set<uint64_t> agreed_shapes_;                // (op, variant, world, len) of the collective calls the ranks have voted on
+    bool fail_next_collective_ = false;
     std::vector<PoolBuf> pool_;
     std::mutex mu_;
     mutable Profiler prof_;

@@ -843,6 +843,11 @@ long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m) {
         return (int)(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->selfcheck_pointwise_z(m) : ctx->m31->selfcheck_pointwise_z(m));
     });
 }
+int ecfft_test_fail_next_collective(ecfft_ctx* ctx) {
+    if (!ctx) return ECFFT_ERR_BAD_ARG;
+    if (ctx->field == ECFFT_FIELD_SECP256K1) ctx->secp->test_fail_next_collective(); else ctx->m31->test_fail_next_collective();
+    return ECFFT_OK;
+}
 int ecfft_ctx_trim(ecfft_ctx* ctx) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     DeviceGuard dev(ctx->device);

@@ -21,6 +21,13 @@ namespace ecfft {
 
 constexpr int kBlock = 256;
 
+// Workgroup barrier that publishes LDS writes only: __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)),
+// which would turn every table request issued ahead of the barrier into a wait AT the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef ECFFT_RADIX_LDSBAR
+#define ECFFT_RADIX_LDSBAR 1                 // 4-byte engine: the barrier behind the early table requests is LDS-only
+#endif
+
 // Value ranges: inside a kernel (registers, LDS) field elements may be in the field's LAZY range (F::tmul / F::tmul_add /
 // F::sub keep them there: [0, p] for M31, canonical for secp256k1); every store to HBM goes through F::canon(), so all
 // arrays between launches, and everything the caller sees, are canonical residues.
@@ -446,7 +453,7 @@ __device__ __forceinline__ void radix_step(typename F::elem* a, const typename F
             for (int m = 0; m < (1 << sp); ++m) { t0[g][(1 << sp) - 1 + m] = ldt(ta, off + (uint32_t)m * tstride); t1[g][(1 << sp) - 1 + m] = ldt(tb, off + (uint32_t)m * tstride); }
         }
     }
-    __syncthreads();
+    if (ECFFT_RADIX_LDSBAR) lds_barrier(); else __syncthreads();          // the constants requested above stay in flight across it
 #pragma unroll 1
     for (uint32_t hf = 0; hf < halves; ++hf, a += hstride) {
         E x[NG][G];
@@ -557,7 +564,6 @@ __device__ __forceinline__ void lds_extend_fast(typename F::elem* a, const typen
     __syncthreads();
 }
 
-__device__ __forceinline__ void lds_barrier();
 // Row-kernel sweeps of a 32-byte field, one pair per thread (tile = 2 * BLK elements), with the two table constants of the NEXT
 // sweep requested before the barrier that ends the current one (see col_stages_pipe).  Pair distances 2^lh_from .. 2^lh_to
 // (downwards for DEC, upwards otherwise), table entry e - 2h + (pair index mod h).  Ends with a barrier.
@@ -813,10 +819,6 @@ __device__ __forceinline__ void col_stage_sweep(typename F::elem* tile, const ty
         else { tile[lo] = F::tmul_add(pa[i], b, a); tile[hi] = F::tmul_add(pb[i], b, a); }
     }
 }
-
-// Workgroup barrier that publishes LDS writes only: __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)),
-// which would turn every table request issued ahead of the barrier into a wait AT the barrier.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #ifndef ECFFT_COL_PIPE
 #define ECFFT_COL_PIPE 1

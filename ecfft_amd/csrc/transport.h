@@ -22,7 +22,7 @@ struct P2P { int peer; void* ptr; size_t bytes; };
 
 class Transport {
 public:
-    virtual ~Transport() { for (hipEvent_t e : ev_) (void)hipEventDestroy(e); }
+    virtual ~Transport() { for (hipEvent_t e : ev_) (void)hipEventDestroy(e); if (vote_dev_) (void)hipFree(vote_dev_); }
     int rank = 0, world = 1, device = 0;
     // every send and receive of the call progresses together (ncclGroupStart / ncclGroupEnd semantics); messages between one
     // pair of ranks match in the order given; buffers are device memory; the work is enqueued on `s`
@@ -34,6 +34,27 @@ public:
         ++calls_;
         for (int i = 0; i < ns; ++i) bytes_ += (double)sends[i].bytes;
         return ok;
+    }
+    // Agreement across ALL ranks of the communicator (one int each way with every peer, then a host wait): true iff every rank
+    // passed ok = true.  A collective call whose local preparation failed on one rank (allocation, table build) must not leave
+    // its peers blocked in the exchanges that follow — every rank votes BEFORE the first exchange and all of them back out
+    // together.  Synchronous; used once per (context, call shape) and between the phases of the collective EXIT-shard build.
+    bool vote(bool ok, hipStream_t s) {
+        if (world <= 1) return ok;
+        if (!vote_dev_ && hipMalloc(&vote_dev_, (size_t)(world + 1) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); vote_dev_ = nullptr; }
+        if (!vote_dev_) { fprintf(stderr, "ecfft: no device memory for the agreement buffer\n"); return false; }   // 4*(world+1) bytes: unreachable in practice
+        int mine = ok ? 1 : 0;
+        if (hipMemcpyAsync(vote_dev_ + world, &mine, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+        if (hipStreamSynchronize(s) != hipSuccess) return false;
+        std::vector<P2P> snd, rcv;
+        for (int p = 0; p < world; ++p) if (p != rank) { snd.push_back({p, vote_dev_ + world, sizeof(int)}); rcv.push_back({p, vote_dev_ + p, sizeof(int)}); }
+        if (!do_exchange(snd.data(), (int)snd.size(), rcv.data(), (int)rcv.size(), s)) return false;
+        std::vector<int> all((size_t)world + 1, 0);
+        if (hipStreamSynchronize(s) != hipSuccess) return false;
+        if (hipMemcpy(all.data(), vote_dev_, (size_t)(world + 1) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        bool every = ok;
+        for (int p = 0; p < world; ++p) if (p != rank && all[(size_t)p] != 1) every = false;
+        return every;
     }
     void stats_enable(bool on) { stats_on_ = on; stats_reset(); }
     void stats_reset() { used_ = 0; pairs_.clear(); calls_ = 0; bytes_ = 0; }
@@ -52,6 +73,7 @@ private:
     struct Pair { hipEvent_t a, b; };
     std::vector<hipEvent_t> ev_; size_t used_ = 0; std::vector<Pair> pairs_;
     bool stats_on_ = false; uint64_t calls_ = 0; double bytes_ = 0;
+    int* vote_dev_ = nullptr;
 };
 
 // ---- RCCL, bound at run time -------------------------------------------------------------------------------------------

@@ -181,6 +181,13 @@ int ecfft_build_exit_shard(int field, size_t n, int device, ecfft_comm* comm, ec
 #define ECFFT_LAYOUT_CYCLIC 1
 int ecfft_extend_sharded_layout(ecfft_ctx* ctx, ecfft_comm* comm, const void* in, void* out, size_t e, int moiety, int in_layout,
                                 int out_layout, void* stream);
+/* Failure on ONE rank: the first time a context sees a sharded call of a given shape (op, size, layout, world) every rank
+ * prepares its temporaries and the ranks AGREE on the outcome (one int each way, host wait) before the first exchange — if any
+ * rank failed, all of them return ECFFT_ERR_HIP and none is left blocked in ncclRecv.  That first call is therefore synchronous;
+ * later calls of the shape reuse the pinned temporaries, cannot fail locally and are asynchronous.  ecfft_build_exit_shard votes
+ * after its local part, at every level and on its final status.  ecfft_test_fail_next_collective (test hook) makes the local
+ * preparation of the context's next such call report failure. */
+int ecfft_test_fail_next_collective(ecfft_ctx* ctx);
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 

@@ -341,3 +341,71 @@ def test_exit_shard_context_on_one_gpu(field, n, P):
         assert torch.equal(got[r], want[r * c:(r + 1) * c]), (field, n, P, r)
         if n >= 1 << 16:
             assert got[("bytes", r)] < full_bytes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["extend", "enter", "exit"])
+def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op):
+    """a sharded call whose local preparation fails on ONE rank (allocation failure; injected here with
+    ecfft_test_fail_next_collective) must return an error on EVERY rank — the ranks vote before the first exchange — and must not
+    leave the peers blocked in a receive.  The next call (nothing injected) succeeds on all ranks and is bit-exact."""
+    import torch
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS["secp256k1"]
+    P, n = 2, 1 << 12
+    c = n // P
+    full = F.build_fftree(2 * n)
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+    x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = {"extend": lambda: full.extend(x, ecfft_amd.Moiety.S1), "enter": lambda: full.enter(x), "exit": lambda: full.exit(x)}[op]()
+    torch.cuda.synchronize()
+    L, first, second = FT.lib(), {}, {}
+
+    def call(ctx, comm, mine):
+        if op == "extend":
+            return ctx.extend_sharded(comm, mine, n, ecfft_amd.Moiety.S1)
+        return ctx.enter_sharded(comm, mine, n) if op == "enter" else ctx.exit_sharded(comm, mine, n)
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        ctx = F.build_fftree(2 * n)                      # full contexts accept every sharded call
+        mine = x[rank * c:(rank + 1) * c].clone()
+        if rank == 1:
+            assert L.ecfft_test_fail_next_collective(ctx._h) == 0
+        try:
+            call(ctx, comm, mine); first[rank] = "ok"
+        except FT.EcfftError:
+            first[rank] = "error"
+        second[rank] = call(ctx, comm, mine)
+
+    _thread_ranks(P, body)
+    torch.cuda.synchronize()
+    assert first == {0: "error", 1: "error"}, first       # rank 0 did nothing wrong and still backs out, together with rank 1
+    for r in range(P):
+        assert torch.equal(second[r], want[r * c:(r + 1) * c]), (op, r)
+
+
+@pytest.mark.gpu
+def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(monkeypatch):
+    """the collective ecfft_build_exit_shard votes after its local part: with rank 1's local part failing, rank 0's build returns an
+    error too instead of waiting for exchanges that never come"""
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS["m31"]
+    monkeypatch.setenv("ECFFT_TEST_FAIL_BUILD_RANK", "1")
+    res = {}
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        try:
+            res[rank] = "built" if F.build_exit_shard(1 << 12, comm) is not None else "none"
+        except FT.EcfftError:
+            res[rank] = "error"
+
+    _thread_ranks(2, body)
+    assert res == {0: "error", 1: "error"}, res
+    monkeypatch.delenv("ECFFT_TEST_FAIL_BUILD_RANK")
+    _thread_ranks(2, lambda rank, make_comm: res.__setitem__(rank, F.build_exit_shard(1 << 12, make_comm()) is not None))
+    assert res == {0: True, 1: True}
