@@ -58,6 +58,11 @@ pub mod ffi {
         pub fn ecfft_degree(ctx: *mut EcfftCtx, evals: *const c_void, n: usize, mem: i32, stream: *mut c_void, degree: *mut usize) -> i32;
         pub fn ecfft_tree_table(ctx: *mut EcfftCtx, m: usize, which: i32, host_out: *mut c_void, cap: usize, count: *mut usize) -> i32;
         pub fn ecfft_ctx_device_bytes(ctx: *const EcfftCtx) -> usize;
+        pub fn ecfft_ctx_trim(ctx: *mut EcfftCtx) -> i32;
+        // FFTree wire format (impl CanonicalSerialize / CanonicalDeserialize for FFTree<F>, src/fftree.rs:507-660)
+        pub fn ecfft_fftree_serialize(ctx: *mut EcfftCtx, compress: i32, buf: *mut c_void, cap: usize, len: *mut usize) -> i32;
+        pub fn ecfft_fftree_deserialize(field: i32, bytes: *const c_void, len: usize, compress: i32, device: i32, verify: i32, out: *mut *mut EcfftCtx) -> i32;
+        pub fn ecfft_tree_rational_maps(ctx: *mut EcfftCtx, map_num3_out: *mut c_void, map_den3_out: *mut c_void) -> i32;
         // one transform split over the GPUs of a node, one process per GPU (device pointers; see ecfft_hip.h)
         pub fn ecfft_comm_get_unique_id(id_out: *mut c_void) -> i32; // ECFFT_COMM_ID_BYTES = 128
         pub fn ecfft_comm_init_rank(id: *const c_void, world: i32, rank: i32, device: i32, out: *mut *mut EcfftComm) -> i32;
@@ -292,6 +297,43 @@ impl<F: HipField> HipFFTree<F> {
     /// leaves of the subtree with m leaves = `subtree_with_size(m).f.leaves()` (src/fftree.rs:471-478)
     pub fn eval_domain(&self, m: usize) -> Vec<F> {
         self.table(m, ffi::TBL_F).split_off(m)
+    }
+
+    /// `CanonicalSerialize::serialize_compressed / serialize_uncompressed` of `FFTree<F>` (src/fftree.rs:510-554): the bytes the
+    /// crate itself would write for this tree (`ark_serialize::Compress::Yes` leaves the three inverse tables out, :536-541)
+    pub fn serialize(&self, compress: ark_serialize::Compress) -> Vec<u8> {
+        let c = matches!(compress, ark_serialize::Compress::Yes) as i32;
+        let mut len = 0usize;
+        check(unsafe { ffi::ecfft_fftree_serialize(self.ctx, c, core::ptr::null_mut(), 0, &mut len) });
+        let mut buf = vec![0u8; len];
+        check(unsafe { ffi::ecfft_fftree_serialize(self.ctx, c, buf.as_mut_ptr().cast(), len, &mut len) });
+        buf
+    }
+    /// `CanonicalDeserialize::deserialize_compressed / deserialize_uncompressed` (src/fftree.rs:600-660): a file written by the crate
+    /// (`README.md:26-41` build.rs flow) becomes a device-resident tree.  `verify`: compare every table of the file with the one
+    /// recomputed from its point set and reject the file (`None`) on a mismatch; malformed input is `None` as well.
+    pub fn deserialize(bytes: &[u8], compress: ark_serialize::Compress, device: i32, verify: bool) -> Option<Self> {
+        let c = matches!(compress, ark_serialize::Compress::Yes) as i32;
+        let mut ctx = core::ptr::null_mut();
+        match unsafe { ffi::ecfft_fftree_deserialize(F::FIELD_ID, bytes.as_ptr().cast(), bytes.len(), c, device, verify as i32, &mut ctx) } {
+            ffi::ERR_BAD_ARG | ffi::ERR_NOT_POW2 => None,
+            rc => {
+                check(rc);
+                Some(Self { ctx, _f: PhantomData })
+            }
+        }
+    }
+    /// the `pub rational_maps` field (src/fftree.rs:28) as (numerator, denominator) coefficient triples, low -> high, zero padded
+    pub fn rational_maps(&self) -> Vec<([F; 3], [F; 3])> {
+        let ln = self.size().trailing_zeros() as usize;
+        let mut num = vec![F::zero(); 3 * ln.max(1)];
+        let mut den = vec![F::zero(); 3 * ln.max(1)];
+        check(unsafe { ffi::ecfft_tree_rational_maps(self.ctx, num.as_mut_ptr().cast(), den.as_mut_ptr().cast()) });
+        (0..ln).map(|k| ([num[3 * k], num[3 * k + 1], num[3 * k + 2]], [den[3 * k], den[3 * k + 1], den[3 * k + 2]])).collect()
+    }
+    /// give the pooled temporaries of the algorithm wrappers back to the device (ecfft_ctx_trim)
+    pub fn trim(&self) {
+        check(unsafe { ffi::ecfft_ctx_trim(self.ctx) });
     }
 
     /// `FFTree::subtree_with_size` (src/fftree.rs:489-496): the chain lives in one context, so this is a size check

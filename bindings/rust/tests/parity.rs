@@ -95,3 +95,25 @@ fn too_small_tree_panics_like_the_reference() {
 fn build_fftree_returns_none_beyond_two_adicity() {
     assert!(HipFFTree::<ecfft::m31::Fp>::build_fftree(1 << 29).is_none()); // src/ec.rs:513-515
 }
+
+/// The wire format: bytes written by the crate load into the device tree, and the device tree writes the crate's bytes back
+/// (src/fftree.rs:507-660; the reference's own tests: deserialized_{un,}compressed_tree_works, src/lib.rs:154-186).
+#[test]
+fn wire_format_round_trips_with_the_crate() {
+    use ark_serialize::{CanonicalDeserialize, CanonicalSerialize, Compress};
+    type F = ecfft::m31::Fp;
+    let cpu = F::build_fftree(64).unwrap();
+    for compress in [Compress::Yes, Compress::No] {
+        let mut bytes = Vec::new();
+        cpu.serialize_with_mode(&mut bytes, compress).unwrap();
+        let gpu = HipFFTree::<F>::deserialize(&bytes, compress, 0, true).expect("crate-written file must load and verify");
+        assert_eq!(gpu.serialize(compress), bytes, "device tree re-serialises to the crate's bytes");
+        let back = ecfft::FFTree::<F>::deserialize_with_mode(&gpu.serialize(compress)[..], compress, ark_serialize::Validate::Yes).unwrap();
+        let v: Vec<F> = rand_vec(64, 5);
+        assert_eq!(back.enter(&v), cpu.enter(&v));
+        assert_eq!(gpu.enter(&v), cpu.enter(&v));
+    }
+    let mut bytes = Vec::new();
+    cpu.serialize_compressed(&mut bytes).unwrap();
+    assert!(HipFFTree::<F>::deserialize(&bytes[..bytes.len() - 1], Compress::Yes, 0, true).is_none(), "truncated file");
+}

@@ -773,13 +773,13 @@ public:
                 // builds fall back to the run-time-tile kernel)
                 constexpr bool ct_row = sizeof(E) == 4 ? ((size_t)1 << kLogTileMax) == (size_t)kBlockRow * 16 : (ECFFT_CT_ALL != 0);
                 // matrix-core form of the stages with pair distance <= 8 (mfma_blk16.h): whole 1024-element sub-tiles, >= 4 in-tile stages
-                const bool use_blk16 = sizeof(E) == 32 && kBlockRow == 512 && !mfma_off_ && T.blk16_A[srcpar] && log_tile >= 10 && le - k_first >= 4;
+                const bool use_blk16 = sizeof(E) == 32 && kBlockRow == 512 && kLogTileMax == 10 && !mfma_off_ && T.blk16_A[srcpar] && log_tile == kLogTileMax && le - k_first >= 4;
                 const uint8_t* bA = use_blk16 ? T.blk16_A[srcpar] : nullptr;
                 const unsigned long long* bK = use_blk16 ? T.blk16_K[srcpar] : nullptr;
                 if (log_tile == kLogTileMax + 1 && ct_row)
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
-                else if (log_tile == kLogTileMax && (ct_row || (bA && row_ct_)))   // compile-time tile: +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
+                else if (log_tile == kLogTileMax && (ct_row || bA))   // compile-time tile (always for the matrix-core row passes): +16% on M31 (8 pairs/thread unroll), -3% on secp256k1
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
                 else
@@ -1865,7 +1865,6 @@ private:
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
-    bool row_ct_ = getenv("ECFFT_NO_ROW_CT") == nullptr;               // matrix-core row passes use the compile-time-tile instantiation (no spills there)
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

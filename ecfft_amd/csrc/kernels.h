@@ -636,8 +636,11 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     // stages k_first .. log_e-2 (h >= 2); the two innermost stages (decompose h=1, recombine h=1) act on the
     // same pairs back to back and are merged into out_j = a + c_j*(b - a): 2 multiplies instead of 4
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
+    // the matrix-core form lives in the compile-time-tile instantiation only (1024-element tiles): its four 32 x 32 accumulators
+    // next to the multiply's registers spill a few dwords in the run-time-tile instantiation, which the small tiles keep using
+    constexpr bool kMfma = sizeof(E) == 32 && kBlockRow == 512 && LOG_TILE_CT == 10;
     bool mfma = false;
-    if constexpr (sizeof(E) == 32 && kBlockRow == 512) mfma = blkA != nullptr;
+    if constexpr (kMfma) mfma = blkA != nullptr;
     const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;              // mfma: VALU sweeps only for pair distances >= 16
     // mfma with T == 1024 and a decompose sweep at distance 16 in this kernel: that sweep writes its results in operand form itself
     const bool fuse16 = mfma && T == (uint32_t)Blk16::kSub && k_first < k_dec_end;
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         stage_sweep<F, true, kBlockRow>(tile, np0 + (e - 2 * (size_t)h), dinv + (e - 2 * (size_t)h), lh, npairs, tid, c0t ? c0t + (e - 2 * (size_t)h) : nullptr);
         __syncthreads();
     }
-    if constexpr (sizeof(E) == 32 && kBlockRow == 512) {
+    if constexpr (kMfma) {
         if (mfma) {
             Blk16::APre pre;
             if (fuse16) {                                                // one pair per thread: (idx, idx + 16)

@@ -61,7 +61,12 @@ def check_records(rec, name, F, tree_of, serializer=None, P=None):
         if serializer is not None:
             for mode, compress in (("serialize_compressed", True), ("serialize_uncompressed", False)):
                 if pre + mode in rec:
-                    assert serializer.serialize_fftree(t, P, compress) == bytes.fromhex(rec[pre + mode]), pre + mode
+                    want = bytes.fromhex(rec[pre + mode])
+                    assert serializer.serialize_fftree(t, P, compress) == want, pre + mode
+                    if hasattr(t, "serialize"):         # device tree: the C-ABI writer and reader (ecfft_fftree_serialize / _deserialize)
+                        assert t.serialize(compress) == want, pre + mode + " (C ABI writer)"
+                        back = serializer.deserialize_fftree(P, want, compress, verify=True)
+                        assert back.n == n and back.serialize(compress) == want, pre + mode + " (C ABI reader)"
                     seen += 1
             if pre + "serialized_size_compressed" in rec:
                 assert serializer.serialized_size(P, n, True) == int(rec[pre + "serialized_size_compressed"], 16); seen += 1
@@ -147,3 +152,21 @@ def test_hip_path_against_the_crate(oracle_mod, name):
             cache[n] = P.build_fftree(n)
         return cache[n]
     assert check_records(rec, name, F, tree_of, S, P) >= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIELDS)
+def test_consumer_drives_the_c_abi_wire_format_on_device_trees(oracle_mod, name):
+    """the same consumer on DEVICE trees against an oracle-written dump: every record incl. the two serialisations goes through
+    the HIP path and the C-ABI writer / reader (what test_hip_path_against_the_crate will do with a crate-written dump)"""
+    import ecfft_amd
+    from ecfft_amd import serialize as S
+    rec = parse_pin(oracle_dump(oracle_mod))
+    P = ecfft_amd.FIELDS[name]
+    cache = {}
+
+    def tree_of(n):
+        if n not in cache:
+            cache[n] = P.build_fftree(n)
+        return cache[n]
+    assert check_records(rec, name, oracle_mod.field(name), tree_of, S, P) >= 20
