@@ -1104,6 +1104,25 @@ int ecfft_selftest_field(int field, int op, const void* a, const void* b, const 
     return ECFFT_ERR_BAD_ARG;
 }
 
+int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t n, int device) {
+    if (!matrix256 || !x || !out || !n || n % Blk16::kSub) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    Fe256 *dT = nullptr, *dx = nullptr; uint8_t* dA = nullptr;
+    bool ok = hipMalloc(&dT, 256 * sizeof(Fe256)) == hipSuccess && hipMalloc(&dx, n * sizeof(Fe256)) == hipSuccess &&
+              hipMalloc(&dA, Blk16::kABytes + Blk16::kKWords * 8) == hipSuccess;
+    ok = ok && hipMemcpy(dT, matrix256, 256 * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, x, n * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        unsigned long long* dK = reinterpret_cast<unsigned long long*>(dA + Blk16::kABytes);
+        hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, nullptr, dT, dA, dK);
+        hipLaunchKernelGGL(k_blk16_apply, dim3((unsigned)(n / Blk16::kSub)), dim3(512), 0, nullptr, dx, dA, dK);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dx, n * sizeof(Fe256), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(dT); (void)hipFree(dx); (void)hipFree(dA);
+    return ok ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);

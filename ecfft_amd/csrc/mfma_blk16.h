@@ -313,6 +313,8 @@ struct Blk16 {
     }
 };
 
+__device__ __forceinline__ void blk16_expand(Fe256* Tm, Fe256* csum, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc, uint32_t tid);
+
 // np0 / dinv: decompose tables of the source parity, p0 / p1: recombine tables of the target parity, inner: merged innermost
 // pair (all as the row kernel receives them), e = vector length of the tree (>= 16)
 __global__ __launch_bounds__(256) void k_blk16_build(const Te256* __restrict__ np0, const Te256* __restrict__ dinv, const Te256* __restrict__ p0,
@@ -348,6 +350,12 @@ __global__ __launch_bounds__(256) void k_blk16_build(const Te256* __restrict__ n
         }
         for (int o = 0; o < 16; ++o) Tm[o * 16 + tid] = x[o];      // column tid of T
     }
+    blk16_expand(Tm, csum, Amat, Kc, tid);
+}
+
+// the 256 constants of a 16 x 16 map (shared memory, row-major [output][input], plain residues) -> int8 matrices + accumulator seeds
+__device__ __forceinline__ void blk16_expand(Fe256* Tm, Fe256* csum, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc, uint32_t tid) {
+    using F = Secp256k1; using E = Fe256;
     __syncthreads();
     {
         const uint32_t o = tid >> 4, i = tid & 15;
@@ -373,6 +381,28 @@ __global__ __launch_bounds__(256) void k_blk16_build(const Te256* __restrict__ n
         const E kap = F::sub(F::mul(s, F::from_u32(128)), off);
         for (int g = 0; g < 8; ++g) Kc[tid * 8 + g] = (1ull << 50) + kap.l[g];
     }
+}
+
+// test hook (ecfft_selftest_blk16): the map given explicitly as 256 plain constants
+__global__ __launch_bounds__(256) void k_blk16_from_matrix(const Fe256* __restrict__ T, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc) {
+    __shared__ Fe256 Tm[256];
+    __shared__ Fe256 csum[256];
+    Tm[threadIdx.x] = T[threadIdx.x];
+    blk16_expand(Tm, csum, Amat, Kc, threadIdx.x);
+}
+// test hook: the matrix-core phase alone on tiles of 1024 elements (grid = tiles, 512 threads), in place
+__global__ __launch_bounds__(512) void k_blk16_apply(Fe256* __restrict__ data, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc) {
+    __shared__ Fe256 tile[Blk16::kSub];
+    const uint32_t tid = threadIdx.x;
+    Fe256* g = data + (size_t)blockIdx.x * Blk16::kSub;
+    for (uint32_t j = tid; j < (uint32_t)Blk16::kSub; j += 512) tile[j] = g[j];
+    __syncthreads();
+    Blk16::APre pre = Blk16::prefetch(Amat, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    Blk16::to_operand_form<512>(tile, Blk16::kSub, tid);
+    Blk16::phase(tile, Amat, Kc, tid, pre);
+    Blk16::from_swizzled<512>(tile, Blk16::kSub, tid);
+    for (uint32_t j = tid; j < (uint32_t)Blk16::kSub; j += 512) g[j] = tile[j];
 }
 
 }  // namespace ecfft

@@ -245,6 +245,12 @@ int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
  * directed operands (results next to p and 2^256, carry-out of the second fold) that random data never reaches. */
 int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device);
 
+/* Test hook (secp256k1): the matrix-core form of the innermost 16-point map (ecfft_amd/csrc/mfma_blk16.h) with an EXPLICIT map —
+ * matrix256 = 16 x 16 plain residues < p, row-major [output][input]; x / out = n raw residues (n a multiple of 1024), every aligned
+ * block of 16 is mapped to out_o = sum_i matrix[o][i] * x_i mod p.  Lets the tests reach the carry-out and canonicalisation
+ * branches of the normalisation (identity / -1 / 0 constants, inputs next to 0, p and 2^32 + 977) that a tree's constants never hit. */
+int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t n, int device);
+
 /* Measurement hook: field multiplies per second of the butterfly kernels' table multiply run as a bare dependent chain
  * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot
  * path against beside the HBM roofline. */
