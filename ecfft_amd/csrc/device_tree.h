@@ -195,7 +195,9 @@ public:
     };
     // only_target = 0 / 1: keep only what EXTENDs towards that moiety read (decompose-side tables of the source parity,
     // recombine-side tables of the target parity): half the constants; -1: both directions
-    static size_t shard_set_elems(size_t c, int only_target = -1) { return (only_target < 0 ? 2 : 1) * (13 * c + 128) * kTeElems + 64; }
+    static size_t shard_set_elems(size_t c, int only_target = -1) {
+        return (only_target < 0 ? 2 : 1) * ((13 * c + 128) * kTeElems + (sizeof(E) == 32 ? Blk16::kArenaElems + 8 : 0)) + 64;   // + the matrix-core tables of the rank's row passes
+    }
     bool build_shard_set(unsigned log_m, unsigned log_p, unsigned rank, const E* f, hipStream_t s, int only_target = -1,
                          Tree* tout = nullptr, ShardSet* sout = nullptr) {
         const size_t m = (size_t)1 << log_m, e = m / 2, P = (size_t)1 << log_p, c = e >> log_p, stride = N_ / m;
@@ -277,6 +279,21 @@ public:
                 in[1] = F::mul(F::sub(tp1[0], sp0[0]), sdi[0]);
             });
             T.inner[sg] = to_tables(in, 2, s);
+        }
+        // matrix-core form of the innermost stages for the rank's block-local row passes (their table entries e-16 .. e-2 lie in the
+        // stored range [e - c, e) whenever c >= 16); an EXTEND from parity sg reads the decompose tables of sg and the recombine
+        // tables of 1 - sg
+        T.blk16_A[0] = T.blk16_A[1] = nullptr; T.blk16_K[0] = T.blk16_K[1] = nullptr;
+        if constexpr (sizeof(E) == 32) {
+            if (c >= 16 && !mfma_off_) {
+                for (int sg = 0; sg < 2; ++sg) {
+                    if (only_target >= 0 && sg != 1 - only_target) continue;
+                    uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
+                    unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
+                    hipLaunchKernelGGL(k_blk16_build, dim3(1), dim3(256), 0, s, T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], e, A, K);
+                    T.blk16_A[sg] = A; T.blk16_K[sg] = K;
+                }
+            }
         }
         return hipGetLastError() == hipSuccess;
     }
