@@ -401,3 +401,34 @@ def test_fftree_new_rejects_a_leaf_that_is_a_pole():
     h = ctypes.c_void_p()
     rc = FT.lib().ecfft_fftree_new(F.id, leaves.ctypes.data, n, num.ctypes.data, den.ctypes.data, 0, ctypes.byref(h))
     assert rc == FT.ERR_BAD_ARG and not h.value
+
+
+@pytest.mark.parametrize("log_n", [18, 20])
+def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch):
+    """round 3: for launches of >= 2^18 elements the innermost seven sweeps of every 1024-element tile run on the int8 matrix
+    cores (mfma_blk16.h).  The same library with ECFFT_NO_MFMA=1 (read when a context is built) runs them as VALU sweeps: ENTER,
+    EXIT of arbitrary evaluations, EXTEND both ways and the batched form must agree bit for bit, on random data and on data
+    made of the byte patterns the operand form (xor 0x80) and the signed-digit matrices are most sensitive to."""
+    n = 1 << log_n
+    P = gpu.FIELDS["secp256k1"]
+    t_mfma = P.build_fftree(n)
+    monkeypatch.setenv("ECFFT_NO_MFMA", "1")
+    t_valu = P.build_fftree(n)
+    monkeypatch.delenv("ECFFT_NO_MFMA")
+    rng = np.random.default_rng(0x5EED0318 + log_n)
+    rand = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); rand[:, 3] >>= np.uint64(1)
+    pat = np.zeros((n, 4), dtype=np.uint64)
+    words = np.array([0, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFFFFFFFFFFFFFFFF, 0x0101010101010101, 0x00FF00FF00FF00FF, 1, 0x8000000000000000], dtype=np.uint64)
+    pat[:, 0] = words[rng.integers(0, 8, n)]; pat[:, 1] = words[rng.integers(0, 8, n)]; pat[:, 2] = words[rng.integers(0, 8, n)]
+    pat[:, 3] = words[rng.integers(0, 8, n)] >> np.uint64(1)                    # < 2^255 < p: canonical
+    for data in (rand, pat):
+        ev = t_mfma.enter(data)
+        assert np.array_equal(ev, t_valu.enter(data))
+        assert np.array_equal(t_mfma.exit(data), t_valu.exit(data))
+        assert np.array_equal(t_mfma.exit(ev), data)
+        h = data[: n // 2]
+        for m in (gpu.Moiety.S1, gpu.Moiety.S0):
+            assert np.array_equal(t_mfma.extend(h, m), t_valu.extend(h, m))
+    if log_n == 18:
+        four = np.concatenate([rand[: n // 4]] * 4)                              # 4 polynomials of n/4 per launch: the batched kernels' tiles
+        assert np.array_equal(t_mfma.enter(four, count=4), t_valu.enter(four, count=4))
