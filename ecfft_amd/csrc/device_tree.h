@@ -436,8 +436,10 @@ public:
         std::vector<E> den(2 * (L_ ? L_ : 1));
         for (unsigned k = 0; k < L_; ++k) { den[2 * k] = host_.maps[k].den[0]; den[2 * k + 1] = host_.maps[k].den[1]; }
         den_ = take(2 * (L_ ? L_ : 1));
-        ECFFT_HIP_TRY(hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s));
-        ECFFT_HIP_TRY(hipStreamSynchronize(s));                  // `den` is a stack vector
+        if (hipMemcpyAsync(den_, den.data(), den.size() * sizeof(E), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {             // `den` is a stack vector; fdev must not leak on this path either
+            (void)hipGetLastError(); (void)hipFree(fdev); fdev = nullptr; return false;
+        }
         return true;
     }
     bool build_extend_shard(HostTree<F>&& ht, int device, unsigned log_p, unsigned rank) {

@@ -297,6 +297,8 @@ int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, co
     if (!dev.ok) return ECFFT_ERR_HIP;
     hipStream_t s = (hipStream_t)stream;
     std::lock_guard<std::mutex> guard(ch.lock());
+    OpScope scope(c, s);                                          // after the context's previous call, whatever stream it ran on (staging buffer, pooled temporaries)
+    if (!scope.ok) return ECFFT_ERR_HIP;
     const E *dx = (const E*)x, *dy = (const E*)y; E* dout = (E*)out;
     size_t bytes = cnt * sizeof(E);
     if (mem == ECFFT_MEM_HOST) {
@@ -840,6 +842,8 @@ long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m) {
         DeviceGuard dev(ctx->device);
         if (!dev.ok) return -1;
         std::lock_guard<std::mutex> guard(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->lock() : ctx->m31->lock());
+        OpScope scope(ctx, nullptr);                              // its pooled temporaries may still be in use by the previous asynchronous call
+        if (!scope.ok) return -1;
         return (int)(ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->selfcheck_pointwise_z(m) : ctx->m31->selfcheck_pointwise_z(m));
     });
 }
@@ -1011,6 +1015,8 @@ int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t
     if (!ctx || shard_only(ctx)) return ECFFT_ERR_BAD_ARG;
     DeviceGuard dev(ctx->device);
     if (!dev.ok) return ECFFT_ERR_HIP;
+    // reads immutable tables only (its device temporaries are its own hipMalloc blocks, not the pool): no ordering against
+    // transform calls in flight is needed
     return guarded([&] { return ctx->field == ECFFT_FIELD_SECP256K1 ? table_of(*ctx->secp, m, which, host_out, cap, count)
                                                                     : table_of(*ctx->m31, m, which, host_out, cap, count); });
 }
