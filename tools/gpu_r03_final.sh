@@ -16,6 +16,7 @@ SIZES=11,12,16,18,20,22 python tools/small_sizes.py m31 >> $O/small_sizes.txt 2>
 ECFFT_NO_MFMA=1 python tools/small_sizes.py secp256k1 > $O/small_sizes_no_mfma.txt 2>&1
 g++ -O2 -std=c++17 -Iinclude examples/bench_fftree.cpp -Lecfft_amd -lecfft_hip -Wl,-rpath,$PWD/ecfft_amd -Wl,--allow-shlib-undefined -o /tmp/bench_fftree && /tmp/bench_fftree > $O/bench_fftree.txt 2>&1
 python tools/build_only.py > $O/build_times.txt 2>&1
+(cd tools/ubench && CLOCK_R3_ONLY=1 ./clock) > $O/clock_ubench_r3.txt 2>&1
 (cd tools/ubench && ./mfma_mul 2048 50 && ./mfma_mul_xstamps 512 10 | grep -A9 "grid 1)") > $O/ubench_mfma_mul.txt 2>&1
 python tools/big_sizes_check.py > $O/big_sizes.txt 2>&1
 python tools/shard_emulate.py secp256k1 22 8 > $O/shard_emulate.txt 2>&1

@@ -3,7 +3,7 @@
 // guide's "2 cycles per plain wave64 VALU instruction": each kernel brackets its instruction loop with s_memtime
 // (shader-clock ticks) and wall_clock64() (constant 100 MHz), so
 //     effective clock = d(s_memtime) / d(wall_clock64) * 100 MHz,
-//     cycles per wave-instruction per SIMD = d(s_memtime) / (waves_per_SIMD * ITER * ops_per_iter).
+//     cycles per wave-instruction per SIMD = launch wall time x effective clock / (wave-instructions per SIMD of the launch).
 // Build: hipcc --offload-arch=gfx950 -O3 -o clock clock.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -134,9 +134,13 @@ void run(const char* name, K kern, uint32_t* d_out, Stamp* d_st, double ops_per_
         double cyc = 0, wall = 0; for (int i = 0; i < blocks; ++i) { cyc += h[i].cyc; wall += h[i].wall; }
         cyc /= blocks; wall /= blocks;
         double mhz = cyc / wall * 100.0;
-        double per_inst = cyc / (wps * (double)iters * ops_per_iter);
-        double nominal = best * 1e-3 * 2.4e9 / ((double)blocks * 4 * iters * ops_per_iter / 1024.0);
-        printf("%-18s waves/SIMD %d: %7.3f ms  eff.clock %6.0f MHz  %5.2f shader-cyc/wave-inst/SIMD  (%5.2f if priced at 2.4 GHz wall)\n",
+        // cycles per wave-instruction per SIMD from the WALL time of the whole launch at the clock measured inside it.  (Round 2 also
+        // printed d(s_memtime) / (wps * iters * ops) per block, which assumes all `wps` requested blocks of a CU are resident together:
+        // kernels whose registers allow fewer waves per SIMD run their blocks in turns and that column read up to 2.3x too low.)
+        double insts_per_simd = (double)blocks * 4 * iters * ops_per_iter / 1024.0;
+        double per_inst = best * 1e-3 * mhz * 1e6 / insts_per_simd;
+        double nominal = best * 1e-3 * 2.4e9 / insts_per_simd;
+        printf("%-18s blocks/CU %d: %7.3f ms  eff.clock %6.0f MHz  %5.2f cyc/wave-inst/SIMD at that clock  (%5.2f if priced at 2.4 GHz)\n",
                name, wps, best, mhz, per_inst, nominal);
     }
 }
