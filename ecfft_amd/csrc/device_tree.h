@@ -127,6 +127,7 @@ public:
         // (F::telem each); + f (2N) + den coefficients
         size_t total = 2 * N_ + 64;
         for (unsigned l = 0; l <= L_; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
+        total += low16_elems();
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         f_ = take(2 * N_);
@@ -149,6 +150,7 @@ public:
         for (unsigned l = 0; l <= L_; ++l) {
             if (!build_tree(l, s)) return false;
         }
+        if (!build_low16(L_, s)) return false;
         ECFFT_HIP_TRY(hipStreamSynchronize(s));
         if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
         temps_free();
@@ -485,6 +487,7 @@ public:
         size_t total = 64 + 2 * L_ + 4096;
         for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
         total += log_p * (shard_set_elems(c, 1) + c + 64);
+        total += low16_elems();
         ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
         arena_cap_ = total; arena_used_ = 0;
         E* fdev = nullptr;
@@ -495,6 +498,7 @@ public:
         create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
         trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
         for (unsigned l = 0; l <= lc; ++l) { if (!build_tree(l, s)) { f_ = nullptr; return false; } }
+        if (!build_low16(lc, s)) { f_ = nullptr; return false; }
         for (size_t Q = 2; Q <= P; Q *= 2) {
             const size_t half = Q / 2, m = c * Q;
             const unsigned lm = ilog2(m);
@@ -556,6 +560,7 @@ public:
                 size_t total = 64 + 3 * L_ + 4096;
                 for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
                 total += log_p * (shard_set_elems(hc) + 5 * c + 256);
+                total += low16_elems();
                 ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
                 arena_cap_ = total; arena_used_ = 0;
                 if (!upload_points(fdev, s)) return false;
@@ -564,6 +569,7 @@ public:
                 create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
                 trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
                 for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
+                if (!build_low16(lc, s)) return false;
                 lc_inv = take(L_);
                 std::vector<E> h(L_, F::one());
                 for (unsigned k = 0; k < L_; ++k) h[k] = F::inv(host_.maps[k].num[2]);
@@ -1682,6 +1688,27 @@ private:
         }
     }
 
+    // The four lowest levels of ENTER and of EXIT as ONE 16 x 16 map each for the matrix cores (LevelTables::low16_A, read by the
+    // 1024-element low-level kernels): every 16-block of a transform goes through the same levels on the same tables, so the maps
+    // are the images of the 16 unit vectors under this context's own level code (16 transforms of 16 points in one batched call).
+    static size_t low16_elems() { return sizeof(E) == 32 ? 2 * (Blk16::kArenaElems + 8) : 0; }
+    bool build_low16(unsigned l_top, hipStream_t s) {
+        if constexpr (sizeof(E) == 32) {
+            if (l_top < kLogLow || mfma_off_ || low16_off_) return true;
+            Tree& T = trees_[4];
+            E* I = temp(256); E* O = temp(256);
+            foreach_n(s, 256, [=] __device__(size_t j) { I[j] = ((j >> 4) == (j & 15)) ? F::one() : F::zero(); });
+            for (int dir = 0; dir < 2; ++dir) {
+                if (dir == 0) enter_levels(I, O, 16, 16, s, scratch_, 1, 4); else exit_levels(I, O, 16, 16, s, scratch_, 4, 1);
+                uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
+                unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
+                hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, s, O, A, K, true);
+                T.low16_A[dir] = A; T.low16_K[dir] = K;
+            }
+        }
+        return hipGetLastError() == hipSuccess;
+    }
+
     bool build_tree(unsigned l, hipStream_t s) {
         Tree& T = trees_[l];
         size_t m = (size_t)1 << l, e = m / 2;
@@ -1884,6 +1911,7 @@ private:
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
+    bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

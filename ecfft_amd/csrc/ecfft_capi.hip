@@ -1121,7 +1121,7 @@ int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t
     ok = ok && hipMemcpy(dT, matrix256, 256 * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, x, n * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
         unsigned long long* dK = reinterpret_cast<unsigned long long*>(dA + Blk16::kABytes);
-        hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, nullptr, dT, dA, dK);
+        hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, nullptr, dT, dA, dK, false);
         hipLaunchKernelGGL(k_blk16_apply, dim3((unsigned)(n / Blk16::kSub)), dim3(512), 0, nullptr, dx, dA, dK);
         ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dx, n * sizeof(Fe256), hipMemcpyDeviceToHost) == hipSuccess;
     }

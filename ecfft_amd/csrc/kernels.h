@@ -1147,6 +1147,9 @@ struct LevelTables {
     // blk16_A[srcpar] / blk16_K[srcpar]: the innermost 16-point map of an EXTEND from parity srcpar as int8 matrices + accumulator
     // seeds for the matrix cores (mfma_blk16.h); nullptr: the VALU sweeps run (4-byte fields, trees with e < 16, shard contexts)
     const uint8_t* blk16_A[2]; const unsigned long long* blk16_K[2];
+    // low16_A / _K (only in the entry of the tree with 16 leaves): levels 1..4 of ENTER [0] and levels 4..1 of EXIT [1] of a 16-block
+    // as ONE 16 x 16 map in the same form - every 16-block of a transform goes through the same four levels on the same tables
+    const uint8_t* low16_A[2]; const unsigned long long* low16_K[2];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1375,7 +1378,20 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
         for (uint32_t j = tid; j < T; j += BLK) cur[j] = src[base + j];
     }
     __syncthreads();
-    for (uint32_t l = 1; l <= log_tile; ++l) {
+    uint32_t l_first = 1;
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) {
+        // levels 1..4 on the matrix cores: one 16 x 16 map per 16-block (LevelTables::low16_A)
+        const uint8_t* lA = trees[4].low16_A[0];
+        if (lA) {
+            Blk16::APre pre = Blk16::prefetch(lA, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            Blk16::to_operand_form<BLK>(cur, T, tid);
+            Blk16::phase(cur, lA, trees[4].low16_K[0], tid, pre);
+            Blk16::from_swizzled<BLK>(cur, T, tid);
+            l_first = 5;
+        }
+    }
+    for (uint32_t l = l_first; l <= log_tile; ++l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
         if constexpr (kQuad) {
@@ -1504,7 +1520,10 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
         for (uint32_t j = tid; j < T; j += BLK) cur[j] = src[base + j];
     }
     __syncthreads();
-    for (uint32_t l = log_tile; l >= 1; --l) {
+    uint32_t l_last = 1;
+    const uint8_t* lA = nullptr;
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) { lA = trees[4].low16_A[1]; if (lA) l_last = 5; }
+    for (uint32_t l = log_tile; l >= l_last; --l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
         if constexpr (kQuad) {
@@ -1620,6 +1639,15 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
             cur[bb + i] = u[c]; cur[bb + e + i] = v[c];
         }
         __syncthreads();
+    }
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) {
+        if (lA) {               // levels 4..1 on the matrix cores: one 16 x 16 map per 16-block
+            Blk16::APre pre = Blk16::prefetch(lA, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            Blk16::to_operand_form<BLK>(cur, T, tid);
+            Blk16::phase(cur, lA, trees[4].low16_K[1], tid, pre);
+            Blk16::from_swizzled<BLK>(cur, T, tid);
+        }
     }
     if constexpr (kQuad) {
         if (qio) {

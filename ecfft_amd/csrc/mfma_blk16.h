@@ -383,11 +383,12 @@ __device__ __forceinline__ void blk16_expand(Fe256* Tm, Fe256* csum, uint8_t* __
     }
 }
 
-// test hook (ecfft_selftest_blk16): the map given explicitly as 256 plain constants
-__global__ __launch_bounds__(256) void k_blk16_from_matrix(const Fe256* __restrict__ T, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc) {
+// the map given explicitly as 256 plain constants, row-major [output][input] (test hook ecfft_selftest_blk16)
+// (also DeviceChain::build_low16: the four lowest ENTER / EXIT levels of a 16-block, images of the unit vectors = columns, `transposed`)
+__global__ __launch_bounds__(256) void k_blk16_from_matrix(const Fe256* __restrict__ T, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc, bool transposed) {
     __shared__ Fe256 Tm[256];
     __shared__ Fe256 csum[256];
-    Tm[threadIdx.x] = T[threadIdx.x];
+    Tm[threadIdx.x] = T[transposed ? (threadIdx.x & 15u) * 16u + (threadIdx.x >> 4) : threadIdx.x];
     blk16_expand(Tm, csum, Amat, Kc, threadIdx.x);
 }
 // test hook: the matrix-core phase alone on tiles of 1024 elements (grid = tiles, 512 threads), in place
