@@ -572,7 +572,11 @@ def build_roofline(args, F, n, classes, step_s, device):
         xe_, xx_ = executed_mul(n)
         out["clock_mhz_under_multiply_load"] = clock_mhz
         tot_mfma = sum((cls_ctr.get(c["name"]) or {}).get("SQ_INSTS_VALU_MFMA_I8", 0.0) * c["launches"] / args.steps for c in live)
-        on_mfma = 14.0 * tot_mfma           # a 1024-element phase = 512 MFMAs in place of 7 sweeps x 1024 multiplies (mfma_blk16.h)
+        # a 1024-element phase = 512 MFMAs.  In an EXTEND it stands for 7 sweeps x 1024 multiplies (14 per MFMA, mfma_blk16.h); the
+        # low16 phases of k_enter_low / k_exit_low (n/2 MFMAs each per transform, launches of >= 2^18 elements) stand for levels 1..4 =
+        # 19 n resp. 34 n multiplies of executed_mul's closed forms (38 / 68 per MFMA)
+        low16 = n // 2 if (tot_mfma > 0 and n >= (1 << 18) and not os.environ.get("ECFFT_NO_LOW16") and args.field != "m31") else 0
+        on_mfma = 14.0 * max(tot_mfma - 2 * low16, 0.0) + (38.0 + 68.0) * low16
         valu_mul = max(xe_ + xx_ - on_mfma, 0.0)
         out["valu"] = {"executed_mul_per_step": xe_ + xx_, "of_which_on_matrix_cores": on_mfma, "valu_mul_per_step": valu_mul,
                        "achieved": valu_mul / step_s, "peak": max(ceil4, ceil8), "unit": "mul/s",

@@ -9,6 +9,7 @@ mkdir -p profiles/r03; cp $O/counters_secp256k1_20.json $O/counters_m31_24.json 
 bash tools/profile_gpu.sh r03_bench k_stages_lds 380 > /dev/null 2>&1; mkdir -p $O/bench_trace; cp gpurun_out/prof_r03_bench/{command.txt,kernel_stats.md,kernel_hot.json,bench_line.json,pmc_FETCH_SIZE_hot.json,pmc_WRITE_SIZE_hot.json,pmc_SQ_WAVES_hot.json} $O/bench_trace/ 2>/dev/null
 python bench.py 2>/dev/null | grep "^{" > $O/bench_default.json
 ECFFT_NO_MFMA=1 python bench.py --cpu-log-n 0 2>/dev/null | grep "^{" > $O/bench_default_no_mfma.json
+ECFFT_NO_LOW16=1 python bench.py --cpu-log-n 0 2>/dev/null | grep "^{" > $O/bench_default_no_low16.json
 python bench.py --field m31 --log-n 24 --cpu-log-n 0 2>/dev/null | grep "^{" > $O/bench_m31_2e24.json
 python bench.py --mode extend-split --log-n 22 --steps 10 --warmup 2 2>/dev/null | grep "^{" > $O/bench_extend_split_2e22_world1.json
 python tools/small_sizes.py secp256k1 > $O/small_sizes.txt 2>&1
