@@ -275,18 +275,7 @@ def main():
                    "field_mul_per_s_per_gpu": (we_ + wx_) * B * args.steps / tb}
         del big, evb, backb
 
-    # ---- --gpus N > 1: besides the replica line, the north_star partitioning itself — ONE transform with its evaluation domain
-    # split over the ranks (grouped ncclSend/ncclRecv at the top log2 N levels, sharded tables), same process group ----------
-    split_obj = None
-    if world > 1 and (args.split_log_n or args.split_log_e):
-        del tree, coeffs, ev, back
-        torch.cuda.empty_cache()
-        split_obj = {"ranks": world, "transport": "rccl" if backend == "nccl" else f"callback over {backend} (functional test)"}
-        if args.split_log_n:
-            split_obj["enter_exit"] = enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_n)
-        if args.split_log_e:
-            split_obj["extend"] = extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_e)
-
+    out = None
     if rank == 0:
         we, wx = w_mul(n)
         value = (we + wx) * args.steps * world / elapsed
@@ -306,9 +295,47 @@ def main():
             "cpu_baseline": None,
             "batched": batched,
         }
-        if split_obj is not None:
-            out["split"] = split_obj              # N = 1 lines carry no such key (byte-compatible with earlier rounds)
         out.update(split)
+
+    # ---- --gpus N > 1: besides the replica line, the north_star partitioning itself — ONE transform with its evaluation domain
+    # split over the ranks (grouped ncclSend/ncclRecv at the top log2 N levels, sharded tables), same process group.  The replica
+    # measurement above is complete at this point: a watchdog makes sure a fault in the split part (this is the only code of the
+    # repository that a one-GPU lease cannot run over real multi-rank RCCL) costs the `split` object and not the whole line. -----
+    if world > 1 and (args.split_log_n or args.split_log_e):
+        import threading
+        del tree, coeffs, ev, back
+        torch.cuda.empty_cache()
+        split_obj = {"ranks": world, "transport": "rccl" if backend == "nccl" else f"callback over {backend} (functional test)"}
+        limit = float(os.environ.get("ECFFT_SPLIT_TIMEOUT_S", "240"))
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(limit):
+                return
+            if rank == 0:
+                split_obj["error"] = f"the split part did not finish within {limit:.0f} s (ECFFT_SPLIT_TIMEOUT_S); replica line kept"
+                out["split"] = split_obj
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            if args.split_log_n:
+                split_obj["enter_exit"] = enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_n)
+            if args.split_log_e:
+                split_obj["extend"] = extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_e)
+        except Exception as ex:  # a rank that fails here leaves its peers in a collective: the watchdog ends those
+            split_obj["error"] = f"{type(ex).__name__}: {ex}"
+            if rank == 0:
+                out["split"] = split_obj
+                print(json.dumps(out), flush=True)
+            sys.stderr.write(f"bench.py rank {rank}: split part failed: {split_obj['error']}\n")
+            os._exit(0)
+        finished.set()
+        if rank == 0:
+            out["split"] = split_obj              # N = 1 lines carry no such key (byte-compatible with earlier rounds)
+
+    if rank == 0:
         if world == 1 and args.cpu_log_n > 0:
             out["cpu_baseline"] = cpu_baseline(args.field, args.cpu_log_n)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

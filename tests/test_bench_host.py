@@ -105,6 +105,26 @@ def test_gpus2_line_carries_the_split_object():
 
 
 @pytest.mark.gpu
+def test_a_stuck_split_part_costs_the_split_object_not_the_line():
+    """The split part is the only code a one-GPU lease cannot run over multi-rank RCCL.  If it hangs (or raises) on a real
+    node, the replica measurement that precedes it must still be printed: a watchdog emits the line with `split.error`."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ECFFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ECFFT_SPLIT_TIMEOUT_S="0.01")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "12",
+           "--split-log-n", "16", "--split-log-e", "0", "--cpu-log-n", "0", "--batch", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"] is not None
+    assert "did not finish" in d["split"]["error"] and "enter_exit" not in d["split"]
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_is_unchanged_by_the_split_option():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "12", "--cpu-log-n", "0", "--batch", "0"],

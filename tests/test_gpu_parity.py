@@ -432,3 +432,33 @@ def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch):
     if log_n == 18:
         four = np.concatenate([rand[: n // 4]] * 4)                              # 4 polynomials of n/4 per launch: the batched kernels' tiles
         assert np.array_equal(t_mfma.enter(four, count=4), t_valu.enter(four, count=4))
+
+
+def test_low16_maps_equal_the_level_code(gpu, monkeypatch):
+    """round 3: in the 1024-element low-level kernels the four lowest ENTER / EXIT levels of every 16-block are ONE matrix-core map
+    each (DeviceChain::build_low16: images of the unit vectors under the level code itself).  ECFFT_NO_LOW16=1 keeps every other
+    matrix-core phase and runs those levels as VALU sweeps: both forms must agree bit for bit on random data, on byte patterns the
+    operand form is sensitive to, and on data that is non-zero in ONE position of each 16-block (every column of both maps on its own)."""
+    n = 1 << 18
+    P = gpu.FIELDS["secp256k1"]
+    t_map = P.build_fftree(n)
+    monkeypatch.setenv("ECFFT_NO_LOW16", "1")
+    t_lvl = P.build_fftree(n)
+    monkeypatch.delenv("ECFFT_NO_LOW16")
+    rng = np.random.default_rng(0x10316)
+    rand = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); rand[:, 3] >>= np.uint64(1)
+    pat = np.zeros((n, 4), dtype=np.uint64)
+    words = np.array([0, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFFFFFFFFFFFFFFFF, 0x0101010101010101, 0x00FF00FF00FF00FF, 1, 0x8000000000000000], dtype=np.uint64)
+    for w in range(3):
+        pat[:, w] = words[rng.integers(0, 8, n)]
+    pat[:, 3] = words[rng.integers(0, 8, n)] >> np.uint64(1)
+    pm1 = np.tile(np.array([0xFFFFFFFEFFFFFC2E, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64), (n, 1))   # p - 1 everywhere
+    cols = np.zeros((n, 4), dtype=np.uint64)
+    pos = np.arange(n)
+    sel = (pos % 16) == ((pos // 16) % 16)                                       # block b carries its value in position b mod 16
+    cols[sel] = rand[sel]
+    for data in (rand, pat, pm1, cols):
+        ev = t_map.enter(data)
+        assert np.array_equal(ev, t_lvl.enter(data))
+        assert np.array_equal(t_map.exit(data), t_lvl.exit(data))
+        assert np.array_equal(t_map.exit(ev), data)
