@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <set>
+#include <map>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -173,9 +174,9 @@ public:
     // ------------------------------------------------------------------------------------------
     // HBM held by this context between calls: table arena + transform scratch (pooled temporaries of the algorithm wrappers
     // and the host-call staging buffer come and go)
-    size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E) + pool_bytes(); }
+    size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E) + pool_bytes() + full_cyc_bytes_; }
     // ecfft_ctx_trim: give every idle pooled temporary back to the device (between calls; takes the context lock)
-    void trim() { std::lock_guard<std::mutex> g(mu_); temps_trim(0); }
+    void trim() { std::lock_guard<std::mutex> g(mu_); temps_trim(0); (void)hipDeviceSynchronize(); full_cyclic_free(); }
     enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2, kShardExit = 3 };
     int shard_kind() const { return shard_kind_; }
     bool shard_mode() const { return shard_kind_ != kShardNone; }
@@ -912,6 +913,33 @@ public:
         for (size_t q = 0; q < P; ++q) { snd[q] = {gbase + (int)q, from + q * piece, piece * sizeof(E)}; rcv[q] = {gbase + (int)q, to + q * piece, piece * sizeof(E)}; }
         return tr.exchange(snd, (int)P, rcv, (int)P, s);
     }
+    // FULL contexts: the same compact cyclic tables, gathered once per (tree, P, rank, table) from the full stage tables on first
+    // use (entry i'*P + rank of stage k -> offset c - 2*(h_k/P) + i', the layout build_shard_set writes) and kept until the context
+    // is destroyed or trimmed — so the split EXTEND of a full context also runs its log P cyclic stages as one fused pass instead
+    // of log P one-stage launches with stride-P table reads.  nullptr (allocation failed): the caller runs the one-stage kernels.
+    // which: 0 np0, 1 dinv, 2 p0, 3 p1 (stage tables), 4 w, 5 winv (the c cyclic positions i'*P + rank).
+    const TE* full_cyclic_table(const Tree& T, unsigned log_p, unsigned r, int sg, int which, hipStream_t s) const {
+        const uint64_t key = ((uint64_t)T.log_m << 40) | ((uint64_t)log_p << 32) | ((uint64_t)r << 8) | ((uint64_t)sg << 4) | (uint64_t)which;
+        auto it = full_cyc_.find(key);
+        if (it != full_cyc_.end()) return it->second;
+        const size_t e = T.e, P = (size_t)1 << log_p, c = e >> log_p;
+        TE* dst = nullptr;
+        if (hipMalloc(&dst, c * sizeof(TE)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        const TE* src = which == 0 ? T.np0[sg] : which == 1 ? T.dinv[sg] : which == 2 ? T.p0[sg] : which == 3 ? T.p1[sg] : which == 4 ? T.w[sg] : T.winv[sg];
+        if (which >= 4) {
+            foreach_n(s, c, [=] __device__(size_t il) { dst[il] = src[il * P + r]; });
+        } else {
+            (void)hipMemsetAsync(dst, 0, c * sizeof(TE), s);
+            for (unsigned k = 0; k < log_p; ++k) {
+                const size_t h = e >> (k + 1), hl = h >> log_p, offl = c - 2 * hl, off = e - 2 * h;
+                foreach_n(s, hl, [=] __device__(size_t il) { dst[offl + il] = src[off + il * P + r]; });
+            }
+        }
+        full_cyc_[key] = dst; full_cyc_bytes_ += c * sizeof(TE);
+        return dst;
+    }
+    void full_cyclic_free() { for (auto& kv : full_cyc_) (void)hipFree(kv.second); full_cyc_.clear(); full_cyc_bytes_ = 0; }
+
     // Shard contexts keep the cyclic stages' table entries compact and laid out like the stage tables of a length-c vector, so the
     // log_p cyclic stages are the TOP log_p stages of a "length-c EXTEND" on those tables: ONE fused column pass (k_stages_col)
     // instead of log_p one-stage launches, with the 1/W or W scaling of a cyclic-in / cyclic-out call riding on its load / store.
@@ -961,7 +989,18 @@ public:
         const ShardSet& SS = sh ? *sp : kNoSet;
         const auto& cyc_ = SS.cyc; const auto& cycw_ = SS.cycw;               // [parity][np0, dinv, p0, p1] and [parity][w, winv], compact
         bool dec_done = false;
-        if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
+        // full context: compact copies of the cyclic entries, gathered on first use (full_cyclic_table)
+        const TE *fd0 = nullptr, *fd1 = nullptr, *fr0 = nullptr, *fr1 = nullptr, *fwi = nullptr, *fw = nullptr;
+        if (!sh && log_p >= 1 && !full_cyc_off_) {
+            fd0 = full_cyclic_table(T, log_p, r, src, 0, s); fd1 = full_cyclic_table(T, log_p, r, src, 1, s);
+            fr0 = full_cyclic_table(T, log_p, r, target, 2, s); fr1 = full_cyclic_table(T, log_p, r, target, 3, s);
+            if (cyc_in) fwi = full_cyclic_table(T, log_p, r, src, 5, s);
+            if (cyc_out) fw = full_cyclic_table(T, log_p, r, target, 4, s);
+        }
+        const bool fdec = fd0 && fd1 && (!cyc_in || fwi), frec = fr0 && fr1 && (!cyc_out || fw);
+        if (cyc_in && fdec && cyclic_stages_fused(fd0, fd1, in, B, c, log_p, true, fwi, nullptr, s)) {
+            dec_done = true;
+        } else if (cyc_in && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], in, B, c, log_p, true, cycw_[src][1], nullptr, s)) {
             dec_done = true;                                                   // 1/W + every cyclic decompose stage in one pass
         } else if (cyc_in) {   // already cyclic: 1/W_src of positions j'*P + r
             if (sh) ECFFT_LAUNCH(KC_POINTWISE, 0.0, k_scale_by_table<F>, dim3(nblocks(c)), dim3(kBlock), 0, s, B, in, (const TE*)cycw_[src][1], c - 1, c, 1u, 0u);
@@ -975,6 +1014,7 @@ public:
         }
         const size_t npairs = c / 2;
         if (!dec_done && sh && cyclic_stages_fused(cyc_[src][0], cyc_[src][1], B, B, c, log_p, true, nullptr, nullptr, s)) dec_done = true;
+        if (!dec_done && fdec && cyclic_stages_fused(fd0, fd1, B, B, c, log_p, true, nullptr, nullptr, s)) dec_done = true;
         for (unsigned k = 0; k < log_p && !dec_done; ++k) {                    // cyclic shard: top decompose stages, table stride P / offset r
             size_t h = e >> (k + 1), off = e - 2 * h;
             if (sh) {
@@ -996,6 +1036,10 @@ public:
         bool rec_done = false;
         if (sh && cyclic_stages_fused(cyc_[target][2], cyc_[target][3], A, cyc_out ? out : A, c, log_p, false, nullptr, cyc_out ? cycw_[target][0] : nullptr, s)) {
             if (cyc_out) return hipGetLastError() == hipSuccess;               // every cyclic recombine stage + W in one pass
+            rec_done = true;
+        }
+        if (!rec_done && frec && cyclic_stages_fused(fr0, fr1, A, cyc_out ? out : A, c, log_p, false, nullptr, cyc_out ? fw : nullptr, s)) {
+            if (cyc_out) return hipGetLastError() == hipSuccess;
             rec_done = true;
         }
         for (unsigned k = log_p; !rec_done && k-- > 0;) {
@@ -1535,6 +1579,7 @@ private:
     void temps_free() { for (auto& b : pool_) (void)hipFree(b.p); pool_.clear(); }
     void release() {
         temps_free();
+        full_cyclic_free();
         if (arena_) (void)hipFree(arena_);
         if (slab_) { (void)hipFree(slab_); slab_ = nullptr; slab_cap_ = slab_used_ = 0; }
         if (scratch_) (void)hipFree(scratch_);
@@ -1911,6 +1956,8 @@ private:
     std::vector<ShardSet> sets_;                            // per tree: the rank's share of its EXTEND tables (shard contexts)
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
+    mutable std::map<uint64_t, TE*> full_cyc_; mutable size_t full_cyc_bytes_ = 0;   // compact cyclic tables of a FULL context (full_cyclic_table)
+    bool full_cyc_off_ = getenv("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule

@@ -259,6 +259,56 @@ def _thread_ranks(P, body):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("field,e,P", [("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("secp256k1", 1 << 12, 2)])
+def test_full_context_fuses_its_cyclic_stages(field, e, P, monkeypatch):
+    """round 3: a FULL context gathers the stride-P entries of the cyclic stages into compact tables on first use, so its split
+    EXTEND runs the log P cyclic stages as one fused column pass each way (no k_decompose_stage / k_recombine_stage launch) like a
+    shard context does; ECFFT_NO_FULL_CYCLIC=1 keeps the one-stage launches.  All four layouts, both forms == the single-GPU EXTEND."""
+    import torch
+    import ecfft_amd
+    Fp = ecfft_amd.FIELDS[field]
+    c = e // P
+    rng = np.random.default_rng(0xF0CC + P)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, e, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(e, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    ref = Fp.build_fftree(2 * e)
+    expect = {m: ref.extend(x, m) for m in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0)}
+    torch.cuda.synchronize()
+    one_stage = {}
+
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("ECFFT_NO_FULL_CYCLIC", "1")
+        counts = {}
+
+        def body(rank, make_comm):
+            comm = make_comm()
+            t = Fp.build_fftree(2 * e)                      # the env switch is read when a context is built
+            t.profile(True)
+            for m in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
+                for ci in (False, True):
+                    for co in (False, True):
+                        mine = (x[rank::P] if ci else x[rank * c:(rank + 1) * c]).contiguous().clone()
+                        got = t.extend_sharded(comm, mine, e, m, cyclic_in=ci, cyclic_out=co)
+                        want = expect[m][rank::P] if co else expect[m][rank * c:(rank + 1) * c]
+                        assert torch.equal(got.reshape(want.shape), want), (rank, int(m), ci, co)
+            cls = {k["name"]: k["launches"] for k in t.profile_read()}
+            held = t.device_bytes
+            t.trim()                                        # the gathered tables are given back by ecfft_ctx_trim (pinned temporaries stay)
+            counts[rank] = (cls["k_decompose_stage"] + cls["k_recombine_stage"], held - t.device_bytes)
+
+        _thread_ranks(P, body)
+        one_stage[fused] = counts
+    logp = P.bit_length() - 1
+    for rank in range(P):
+        assert one_stage[True][rank][0] == 0 and one_stage[True][rank][1] > one_stage[False][rank][1]
+        assert one_stage[False][rank][0] == 8 * 2 * logp            # 8 calls x (log P decompose + log P recombine) launches
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
                                        ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2),    # chunk 2^20 runs the two-halves schedule
                                        ("secp256k1", 1 << 20, 8)])   # last: the BASELINE metric's size (configs[2]) over P = 8
