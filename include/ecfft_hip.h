@@ -80,10 +80,12 @@ int ecfft_field(const ecfft_ctx* ctx);
 /* test hook: entries of z0_s1 / z1_s0 of the subtree with m leaves (built as the reference does, src/fftree.rs:386-397) that
  * differ from the pointwise isogeny-chain formula the sharded builds use; 0 = identical, -1 = error */
 long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m);
-size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch + pooled temporaries */
+size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch + pooled temporaries (+ gathered cyclic tables) */
 /* The algorithm wrappers (ecfft_redc, ecfft_vanish, ecfft_degree, the sharded transforms ...) keep their temporaries in a
  * per-context pool between calls; the pool is capped (idle blocks beyond twice the transform scratch are freed at the end of a
- * call) and this call returns ALL idle blocks and the host-call staging buffer to the device.  Call between transforms. */
+ * call) and this call returns ALL idle blocks and the host-call staging buffer to the device.  Call between transforms.
+ * A full context that has served sharded EXTENDs also holds compact copies of the cyclic stages' table entries (gathered on
+ * first use, counted by ecfft_ctx_device_bytes); they are returned too and gathered again when needed. */
 int ecfft_ctx_trim(ecfft_ctx* ctx);
 
 /* coefficients -> evaluations on the leaves of T_n (n = len; any power of two <= tree size) */
