@@ -341,7 +341,9 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             out["cpu_baseline_socket"] = cpu_baseline_socket(args.field, args.cpu_log_n)
             out["gpu_over_cpu_socket"] = value / out["cpu_baseline_socket"]["value_extrapolated_to_socket"]
-            out["gpu_over_cpu_socket_note"] = "GPU value / CPU socket figure extrapolated to every physical core of the socket (see cpu_baseline_socket)"
+            out["gpu_over_cpu_threads_measured"] = value / out["cpu_baseline_socket"]["value"]     # against what really ran (cores = the cgroup quota)
+            out["gpu_over_cpu_socket_note"] = ("gpu_over_cpu_socket: GPU value / CPU figure extrapolated to every physical core of the socket; "
+                                               "gpu_over_cpu_threads_measured: GPU value / the measured multi-thread figure (cpu_baseline_socket.cores threads)")
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
