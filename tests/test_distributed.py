@@ -299,6 +299,9 @@ def test_full_context_fuses_its_cyclic_stages(field, e, P, monkeypatch):
             held = t.device_bytes
             t.trim()                                        # the gathered tables are given back by ecfft_ctx_trim (pinned temporaries stay)
             counts[rank] = (cls["k_decompose_stage"] + cls["k_recombine_stage"], held - t.device_bytes)
+            mine = x[rank * c:(rank + 1) * c].contiguous().clone()               # after the trim the tables are gathered again
+            got = t.extend_sharded(comm, mine, e, ecfft_amd.Moiety.S1)
+            assert torch.equal(got.reshape(mine.shape), expect[ecfft_amd.Moiety.S1][rank * c:(rank + 1) * c])
 
         _thread_ranks(P, body)
         one_stage[fused] = counts
