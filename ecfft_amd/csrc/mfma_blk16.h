@@ -298,6 +298,123 @@ struct Blk16 {
         return load_swizzled(sub, tid);
     }
 
+    // ---------------------------------------------------------------------------------------------------------------------
+    // The SMALL-LAUNCH form (round 4): the same map on a 256-element array = 16 blocks (or a 128-element array = 8 blocks), with
+    // v_mfma_i32_16x16x64_i8 (N = 16 columns = the blocks; K = 64 = the bytes of TWO inputs; M = 16 = half of an output's 32
+    // digit rows).  Launches with fewer 1024-element tiles than CUs run on 256-element tiles, which hold half of
+    // a 32 x 32 x 32 MFMA's columns.  Same constant tables as phase(): row group g (0 / 1) of output o and K-step s (inputs 2s,
+    // 2s + 1) is rows 16g .. 16g + 15 of the 32 x 32 matrices (o, 2s) and (o, 2s + 1), i.e. lane l = (q, m) (q = l >> 4,
+    // m = l & 15) reads the 16 bytes that lane 16g + m + 32 (q & 1) of matrix (o, 2s + (q >> 1)) holds in the 32 x 32 x 32 layout.
+    //   A: lane (q, m): row m, K bytes 16q..;  B: lane (q, n): column n = block, K bytes 16q.. = chunk q & 1 of input 2s + (q >> 1);
+    //   D: lane (q, n): column n, rows 4q + r (r = register 0..3)  ->  digit 16 (q & 1) + 8g + 4 (q >> 1) + r of the output.
+    // NW waves (4 or 2); wave w produces the OPW = 16 / NW outputs OPW w .. OPW w + OPW - 1 in sets of four (eight 16 x 16
+    // accumulators per set).  After the MFMAs the four lane quarters hold different digits of the SAME four outputs: a 4 x 4
+    // transpose across the quarters (v_permlane32_swap, then v_permlane16_swap, per accumulator register) gives lane (q, n) all
+    // 32 digits of output (4 set + q) of block n.
+    //   NW = 4            : 256 elements, 256 threads, one result per lane
+    //   NW = 2            : 256 elements, 128 threads, two results per lane (k_exit_low<8,128>'s whole tile: the low16 map)
+    //   NW = 2, DUP8      : 128 elements = 8 blocks, 128 threads (k_exit_low<8,128>'s half-tiles): columns n and n + 8 both carry
+    //                       block n & 7, and lane (q, n) keeps set n >> 3 — one result per lane, every lane busy
+    // `conv()` is called after the first constant matrices have been requested (their latency hides behind it): it must leave
+    // `sub` in operand form and end with a barrier.  Results: canonical residues (plain bytes) at the swizzled chunk positions,
+    // like phase().  Ends with a barrier.  DEPTH: units of 8 constant-matrix loads (1 KiB per wave each) in flight.
+    template <int NW, bool DUP8, int DEPTH = 2, class Conv>
+    __device__ static __forceinline__ void phase_n16(E* sub, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid, Conv&& conv) {
+        static_assert(NW == 4 || NW == 2, "4 or 2 waves");
+        static_assert(!DUP8 || NW == 2, "the 8-block form runs on two waves");
+        constexpr int OPW = 16 / NW, SETS = OPW / 4, NU = 8 * SETS;        // unit u = (K-step u / SETS, set u % SETS)
+        uint4* lds = reinterpret_cast<uint4*>(sub);
+        const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 15, q = L >> 4;
+        const uint32_t blk = DUP8 ? (n & 7u) : n;
+        // constants: matrix (o, i) at (o * 16 + i) * 1024; lane offset inside it 16 * (16g + n + 32 (q & 1))
+        const gchar ap = (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(OPW * w) * NB + (q >> 1)) * 1024 + 16u * (n + 32u * (q & 1u));
+        auto ldA16 = [&](int u, int c) { const int s = u / SETS, oo = 4 * (u % SETS) + (c >> 1); return *(gv4)(ap + ((size_t)oo * NB + 2 * (size_t)s) * 1024 + 256 * (c & 1)); };
+        v4i QA[DEPTH][8];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) QA[d][c] = ldA16(d, c);
+        __builtin_amdgcn_sched_barrier(0);
+        conv();
+        // data: chunk index of (block, K-step s, lane quarter q) is 32 block + 4s + q
+        const char* lb = reinterpret_cast<const char*>(lds);
+        auto ldB = [&](int s) { const uint32_t c = 32u * blk + 4u * (uint32_t)s + q; const uint4 b = *reinterpret_cast<const uint4*>(lb + 16u * ((c & ~15u) | ((c ^ blk) & 15u))); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
+        v4i Bq[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) Bq[s] = ldB(s);
+        v4i acc[SETS][4][2];
+#pragma unroll
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
+            for (int oo = 0; oo < 4; ++oo) { acc[st][oo][0] = v4i{0, 0, 0, 0}; acc[st][oo][1] = v4i{0, 0, 0, 0}; }
+        BLK16_STAMP(1)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            v4i A[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) A[c] = QA[u % DEPTH][c];
+            if (u + DEPTH < NU) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) QA[u % DEPTH][c] = ldA16(u + DEPTH, c);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the requests ABOVE the MFMAs
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[u % SETS][c >> 1][c & 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[c], Bq[u / SETS], acc[u % SETS][c >> 1][c & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        BLK16_STAMP(2)
+        // 4 x 4 transpose across the lane quarters: afterwards lane (q, n) holds what quarters 0..3 held of output 4 set + q
+        int lo[SETS][16], hi[SETS][16];
+#pragma unroll
+        for (int st = 0; st < SETS; ++st)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    auto p02 = __builtin_amdgcn_permlane32_swap((unsigned)acc[st][0][g][r], (unsigned)acc[st][2][g][r], false, false);
+                    auto p13 = __builtin_amdgcn_permlane32_swap((unsigned)acc[st][1][g][r], (unsigned)acc[st][3][g][r], false, false);
+                    auto x01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false);
+                    auto x23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+                    lo[st][8 * g + r] = (int)x01[0];            // quarter 0: digit 8g + r
+                    hi[st][8 * g + r] = (int)x01[1];            // quarter 1: digit 16 + 8g + r
+                    lo[st][4 + 8 * g + r] = (int)x23[0];        // quarter 2: digit 4 + 8g + r
+                    hi[st][4 + 8 * g + r] = (int)x23[1];        // quarter 3: digit 20 + 8g + r
+                }
+        constexpr int NR = DUP8 ? 1 : SETS;                     // results per lane
+        E z[NR]; uint32_t jz[NR];
+        if constexpr (DUP8) {
+            const bool up = (n >> 3) != 0;                       // columns 8..15 duplicate blocks 0..7: they keep the second set
+            int l2[16], h2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { l2[r] = up ? lo[1][r] : lo[0][r]; h2[r] = up ? hi[1][r] : hi[0][r]; }
+            const uint32_t o = OPW * w + 4u * (n >> 3) + q;
+            z[0] = normalise<true>(l2, h2, Kc + o * 8); jz[0] = blk * NB + o;
+        } else {
+#pragma unroll
+            for (int st = 0; st < SETS; ++st) { const uint32_t o = OPW * w + 4u * (uint32_t)st + q; z[st] = normalise<true>(lo[st], hi[st], Kc + o * 8); jz[st] = n * NB + o; }
+        }
+        BLK16_STAMP(3)
+        __syncthreads();        // every operand read of this phase is done: the array can be overwritten
+        BLK16_STAMP(4)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            lds[phys(jz[i], 0)] = make_uint4(z[i].l[0], z[i].l[1], z[i].l[2], z[i].l[3]);
+            lds[phys(jz[i], 1)] = make_uint4(z[i].l[4], z[i].l[5], z[i].l[6], z[i].l[7]);
+        }
+        __syncthreads();
+    }
+    // ... on an array whose element tid the calling thread holds in registers (one element per thread: 256 elements / 4 waves,
+    // or 128 elements / 2 waves).  Returns element tid of the result; ends with a barrier.
+    template <int NW, int DEPTH = 2>
+    __device__ static __forceinline__ E phase_n16_regs(E* sub, const E& x, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid) {
+        phase_n16<NW, NW == 2, DEPTH>(sub, Amat, Kc, tid, [&] {
+            __syncthreads();                                    // readers of the array's previous contents are done
+            store_operand(sub, tid, x);
+            __syncthreads();
+        });
+        return load_swizzled(sub, tid);
+    }
+
     // ---- construction: the 16 x 16 matrix of the tree (the kernels' own stage code applied to the unit vectors), its
     // int8 expansion and the accumulator seeds.  One workgroup of 256 threads per (tree, parity).
     __device__ static inline void signed_digits(const E& c, int8_t d[32]) {
@@ -404,6 +521,28 @@ __global__ __launch_bounds__(512) void k_blk16_apply(Fe256* __restrict__ data, c
     Blk16::phase(tile, Amat, Kc, tid, pre);
     Blk16::from_swizzled<512>(tile, Blk16::kSub, tid);
     for (uint32_t j = tid; j < (uint32_t)Blk16::kSub; j += 512) g[j] = tile[j];
+}
+
+// test hook: the small-launch forms (v_mfma_i32_16x16x64_i8) alone, in place.  MODE 1: 256-element tiles, 256 threads, LDS-resident
+// array (k_enter_low<8,256>'s low16);  2: 256-element tiles, 128 threads (k_exit_low<8,128>'s low16);  3: 128-element tiles, 128
+// threads, element in registers (k_exit_low<8,128>'s half-tiles);  4: 256-element tiles, 256 threads, element in registers (the
+// 256-element row kernel, k_enter_low<8,256>'s EXTEND cores)
+template <int MODE>
+__global__ __launch_bounds__(MODE == 1 || MODE == 4 ? 256 : 128) void k_blk16_apply_n16(Fe256* __restrict__ data, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc) {
+    constexpr int T = MODE == 3 ? 128 : 256, BLK = (MODE == 1 || MODE == 4) ? 256 : 128;
+    __shared__ Fe256 tile[T];
+    const uint32_t tid = threadIdx.x;
+    Fe256* g = data + (size_t)blockIdx.x * T;
+    if constexpr (MODE == 1 || MODE == 2) {
+        for (uint32_t j = tid; j < (uint32_t)T; j += BLK) tile[j] = g[j];
+        __syncthreads();
+        Blk16::phase_n16<MODE == 1 ? 4 : 2, false>(tile, Amat, Kc, tid, [&] { Blk16::to_operand_form<BLK>(tile, T, tid); });
+        Blk16::from_swizzled<BLK>(tile, T, tid);
+        for (uint32_t j = tid; j < (uint32_t)T; j += BLK) g[j] = tile[j];
+    } else {
+        const Fe256 x = g[tid];
+        g[tid] = Blk16::phase_n16_regs<MODE == 4 ? 4 : 2>(tile, x, Amat, Kc, tid);
+    }
 }
 
 }  // namespace ecfft
