@@ -802,6 +802,13 @@ public:
                 const bool use_blk16 = sizeof(E) == 32 && kBlockRow == 512 && kLogTileMax == 10 && !mfma_off_ && T.blk16_A[srcpar] && log_tile == kLogTileMax && le - k_first >= 4;
                 const uint8_t* bA = use_blk16 ? T.blk16_A[srcpar] : nullptr;
                 const unsigned long long* bK = use_blk16 ? T.blk16_K[srcpar] : nullptr;
+                if (sizeof(E) == 32 && log_tile == kLogLowSmall && !row256_off_ && d.st_mode != ST_ENTER && T.c0t[srcpar]) {
+                    // latency regime: one element per thread in registers; round 4: the stages with pair distance <= 8 on the matrix
+                    // cores here too (v_mfma_i32_16x16x64_i8: the 16 blocks of a 256-element tile are one MFMA's columns)
+                    const bool mf = !mfma_off_ && T.blk16_A[srcpar] && le >= 4 && le - k_first >= 4;
+                    ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_row256<F>), dim3((unsigned)(total >> kLogLowSmall)), dim3(256), 0, s, d, T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar],
+                                 le, k_first, T.c0t[srcpar], mf ? T.blk16_A[srcpar] : (const uint8_t*)nullptr, mf ? T.blk16_K[srcpar] : (const unsigned long long*)nullptr);
+                } else
                 if (log_tile == kLogTileMax + 1 && ct_row)
                     ECFFT_LAUNCH(KC_ROW, bytes, (k_stages_lds<F, (int)kLogTileMax + 1>), dim3((unsigned)(total >> log_tile)), dim3(kBlockRow),
                                  ((size_t)sizeof(E)) << log_tile, s, d, T.np0[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], le, k_first, log_tile, T.c0t[srcpar], bA, bK);
@@ -1739,7 +1746,7 @@ private:
     static size_t low16_elems() { return sizeof(E) == 32 ? 2 * (Blk16::kArenaElems + 8) : 0; }
     bool build_low16(unsigned l_top, hipStream_t s) {
         if constexpr (sizeof(E) == 32) {
-            if (l_top < kLogLow || mfma_off_ || low16_off_) return true;
+            if (l_top < kLogLowSmall || mfma_off_ || low16_off_) return true;
             Tree& T = trees_[4];
             E* I = temp(256); E* O = temp(256);
             foreach_n(s, 256, [=] __device__(size_t j) { I[j] = ((j >> 4) == (j & 15)) ? F::one() : F::zero(); });
@@ -1960,6 +1967,7 @@ private:
     bool full_cyc_off_ = getenv("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
+    bool row256_off_ = getenv("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };
 

@@ -757,6 +757,44 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
 }
 
+// forward declaration (defined with the low-level kernels below)
+template <class F, int BLK>
+__device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
+                                             const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
+                                             const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                             const typename F::telem* __restrict__ inner, uint32_t tid,
+                                             const uint8_t* __restrict__ blkA, const unsigned long long* __restrict__ blkK);
+
+// ---------------------------------------------------------------------------------------------
+// Row kernel of the LATENCY regime (32-byte fields, launches with fewer 1024-element tiles than CUs): 256-element
+// tiles, 256 threads, ONE element per thread kept in registers through every in-tile stage (reg_extend32: cross-lane moves for
+// pair distances < 64, LDS above), and — round 4 — the stages with pair distance <= 8 as one 16-point map per block on the
+// matrix cores (v_mfma_i32_16x16x64_i8, Blk16::phase_n16_regs) when blkA != nullptr.  Same stages, same operators and the same
+// results as k_stages_lds on a 256-element tile (ST_ENTER excepted: that operator needs whole [U | V] blocks and keeps the
+// generic kernel).
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256, 2) void k_stages_row256(IoDesc<F> io,
+                                                          const typename F::telem* __restrict__ dinv,
+                                                          const typename F::telem* __restrict__ p0,
+                                                          const typename F::telem* __restrict__ p1,
+                                                          const typename F::telem* __restrict__ inner,
+                                                          uint32_t log_e, uint32_t k_first,
+                                                          const typename F::telem* __restrict__ c0t,
+                                                          const uint8_t* __restrict__ blkA, const unsigned long long* __restrict__ blkK) {
+    using E = typename F::elem;
+    if constexpr (sizeof(E) == 32) {
+        __shared__ E tile[256];
+        const uint32_t tid = threadIdx.x;
+        const size_t pos = ((size_t)blockIdx.x << 8) + tid;
+        const size_t emask = ((size_t)1 << log_e) - 1;
+        tile[tid] = io_load<F>(io, pos, emask);
+        __syncthreads();
+        reg_extend32<F, 256>(tile, 256u, log_e, k_first, c0t, dinv, p0, p1, inner, tid, blkA, blkK);
+        io_store<F>(io, pos, log_e, tile[tid]);
+    }
+}
+
 #ifndef ECFFT_COL_PAD
 #define ECFFT_COL_PAD 0
 #endif
@@ -1184,8 +1222,8 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
                                              const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
                                              const typename F::telem* __restrict__ inner, uint32_t tid,
-                                             const uint8_t* __restrict__ blkA = nullptr, const unsigned long long* __restrict__ blkK = nullptr) {
-    // blkA != nullptr (len == BLK == 512, log_e - k_first >= 4): the stages with pair distance <= 8 run on the matrix cores
+                                             const uint8_t* __restrict__ blkA, const unsigned long long* __restrict__ blkK) {
+    // blkA != nullptr (len == BLK == 512, 256 or 128, log_e - k_first >= 4): the stages with pair distance <= 8 run on the matrix cores
     using E = typename F::elem;
     using TE = typename F::telem;
     static_assert(sizeof(E) == 32, "32-byte fields");
@@ -1201,7 +1239,7 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
     };
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     bool mfma = false;
-    if constexpr (BLK == 512) mfma = blkA != nullptr;
+    if constexpr (BLK == 512 || BLK == 256 || BLK == 128) mfma = blkA != nullptr;
     const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;
     for (uint32_t k = k_first; k < k_dec_end; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
@@ -1214,9 +1252,10 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
             x = F::tmul_add(t, F::sub(B, A), lane_sel<F>(hi, F::zero(), A));   // lo: a + c0t*(b - a)   hi: dinv*(b - a)
         }
     }
-    if constexpr (BLK == 512) {
+    if constexpr (BLK == 512 || BLK == 256 || BLK == 128) {
         if (mfma) {                                                         // len == BLK: every thread holds an element
-            x = Blk16::phase512_regs(a, x, blkA, blkK, tid);
+            if constexpr (BLK == 512) x = Blk16::phase512_regs(a, x, blkA, blkK, tid);
+            else x = Blk16::phase_n16_regs<BLK / 64>(a, x, blkA, blkK, tid);   // small launches: v_mfma_i32_16x16x64_i8
         }
     }
     if (log_e > 0 && k_first <= k_inner && !mfma) {                         // merged innermost stage pair (h = 1)
@@ -1257,6 +1296,9 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     const uint8_t* bA = nullptr; const unsigned long long* bK = nullptr;
     if constexpr (sizeof(E) == 32 && BLK == 512) {
         if (log_e >= 4 && (len == 512u || (len & 1023u) == 0)) { bA = T.blk16_A[srcpar]; bK = T.blk16_K[srcpar]; }
+    }
+    if constexpr (sizeof(E) == 32 && (BLK == 256 || BLK == 128)) {          // latency variants: one element per thread
+        if (log_e >= 4 && len == (uint32_t)BLK) { bA = T.blk16_A[srcpar]; bK = T.blk16_K[srcpar]; }
     }
     if constexpr (sizeof(E) == 32 && ECFFT_REG_ENGINE) {
         if (len <= (uint32_t)BLK && (len & 63u) == 0) {
@@ -1349,7 +1391,7 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
 
 // ENTER levels 1 .. log_tile (src/fftree.rs:143-161 for every block of size <= tile).  LDS: 2*tile elements.
 template <class F, int LOG_TILE, int BLK = kBlockLds>
-__global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 2)) void k_enter_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                           const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -1387,6 +1429,15 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
             __builtin_amdgcn_sched_barrier(0);
             Blk16::to_operand_form<BLK>(cur, T, tid);
             Blk16::phase(cur, lA, trees[4].low16_K[0], tid, pre);
+            Blk16::from_swizzled<BLK>(cur, T, tid);
+            l_first = 5;
+        }
+    }
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 8 && BLK == 256) {
+        // latency variant: the same map on the 16 blocks of the 256-element tile (v_mfma_i32_16x16x64_i8, mfma_blk16.h)
+        const uint8_t* lA = trees[4].low16_A[0];
+        if (lA) {
+            Blk16::phase_n16<4, false>(cur, lA, trees[4].low16_K[0], tid, [&] { Blk16::to_operand_form<BLK>(cur, T, tid); });
             Blk16::from_swizzled<BLK>(cur, T, tid);
             l_first = 5;
         }
@@ -1491,7 +1542,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_enter_low(typename F::
 // EXIT levels log_tile .. 1 (src/fftree.rs:200-224 with redc_impl :232-259 inlined, normalised form, see
 // DeviceChain::exit).  LDS: cur (tile) + G (tile/2) + H (tile/2).
 template <class F, int LOG_TILE, int BLK = kBlockLds>
-__global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
+__global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exit_low(typename F::elem* __restrict__ dst, const typename F::elem* __restrict__ src,
                                                          const LevelTables<F>* __restrict__ trees) {
     using E = typename F::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char ecfft_smem[];
@@ -1522,7 +1573,7 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
     __syncthreads();
     uint32_t l_last = 1;
     const uint8_t* lA = nullptr;
-    if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) { lA = trees[4].low16_A[1]; if (lA) l_last = 5; }
+    if constexpr (sizeof(E) == 32 && ((LOG_TILE == 10 && BLK == 512) || (LOG_TILE == 8 && BLK == 128))) { lA = trees[4].low16_A[1]; if (lA) l_last = 5; }
     for (uint32_t l = log_tile; l >= l_last; --l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
@@ -1646,6 +1697,12 @@ __global__ __launch_bounds__(BLK, ECFFT_MIN_WAVES) void k_exit_low(typename F::e
             __builtin_amdgcn_sched_barrier(0);
             Blk16::to_operand_form<BLK>(cur, T, tid);
             Blk16::phase(cur, lA, trees[4].low16_K[1], tid, pre);
+            Blk16::from_swizzled<BLK>(cur, T, tid);
+        }
+    }
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 8 && BLK == 128) {
+        if (lA) {               // latency variant: 16 blocks on two waves (v_mfma_i32_16x16x64_i8), two results per lane
+            Blk16::phase_n16<2, false>(cur, lA, trees[4].low16_K[1], tid, [&] { Blk16::to_operand_form<BLK>(cur, T, tid); });
             Blk16::from_swizzled<BLK>(cur, T, tid);
         }
     }
