@@ -736,7 +736,8 @@ public:
         if (k_first > k_begin) {                                              // balanced groups of <= kColStages stages
             unsigned log_ct0 = tz < kLogColTileMax ? tz : kLogColTileMax;
             if (small && log_ct0 > kLogLowSmall) log_ct0 = kLogLowSmall;
-            unsigned rmax = kColStages < log_ct0 - 2 ? kColStages : log_ct0 - 2;    // keep rows >= 4 elements (128 B)
+            const unsigned minc = (small && log_ct0 == kLogLowSmall) ? small_min_logc_ : 2u;
+            unsigned rmax = kColStages < log_ct0 - minc ? kColStages : log_ct0 - minc;    // keep rows >= 4 elements (128 B)
             if (rmax < 1) rmax = 1;
             unsigned ncol = k_first - k_begin, ngrp = (ncol + rmax - 1) / rmax;
             unsigned k = k_begin;
@@ -761,6 +762,9 @@ public:
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = 2.0 * sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + extra_last + next_ld->extra_first;
                 const unsigned lv = pair_spans(total, le, P.ka, log_ct, d);
+                if (col256_ok(log_ct, le) && T.c0t[tgt])      // latency regime: one element per thread in registers (reg_col_stages)
+                    ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid256<F>, dim3((unsigned)(total >> log_ct)), dim3(256), 0, s, d, T.p0[tgt], T.p1[tgt], T.c0t[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c);
+                else
                 ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_mid<F>, dim3((unsigned)(total >> (log_ct + lv))), dim3(kBlockLds), (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv, s,
                              d, T.p0[tgt], T.p1[tgt], T.np0[tgt], T.dinv[tgt], le, P.ka, P.kb, log_c, T.c0t[tgt], (uint32_t)lv);
                 return true;
@@ -773,6 +777,10 @@ public:
                 unsigned R = P.kb + 1, log_c = log_ct - R;
                 double hsum = 0; for (unsigned k = P.ka; k <= P.kb; ++k) hsum += (double)(e >> (k + 1));
                 double bytes = sizeof(E) * (2.0 * R * total + 4.0 * hsum * tblw_) + ef->extra;
+                if (col256_ok(log_ct, le))
+                    ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_enter256<F>, dim3((unsigned)(total >> (log_ct + 1))), dim3(512), 0, s,
+                                 (const E*)buf, ef->src, ef->dst, T.p0[tgt], T.p1[tgt], T.xe, T.w[1], T.w1x, le, P.kb, log_c);
+                else
                 ECFFT_LAUNCH(KC_COL, bytes, k_stages_col_enter<F>, dim3((unsigned)(total >> (log_ct + 1))), dim3(kBlockLds),
                              2 * sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R), s,
                              (const E*)buf, ef->src, ef->dst, T.p0[tgt], T.p1[tgt], T.xe, T.w[1], T.w1x, le, P.kb, log_c);
@@ -827,6 +835,10 @@ public:
                 const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
                 const unsigned lv = ct ? pair_spans(total, le, P.ka, log_ct, d) : 0;
                 dim3 grid((unsigned)(total >> (log_ct + lv))); size_t lds = (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv;
+                if (col256_ok(log_ct, le) && lv == 0 && (P.kind != 0 || T.c0t[srcpar])) {
+                    if (P.kind == 0) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col256<F, true>), dim3((unsigned)(total >> log_ct)), dim3(256), 0, s, d, T.c0t[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
+                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col256<F, false>), dim3((unsigned)(total >> log_ct)), dim3(256), 0, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
+                } else
                 if (P.kind == 0) {
                     if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
                     else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
@@ -851,6 +863,8 @@ public:
         const size_t nspans = total >> (le - ka);
         return (nspans >= 2 && (nspans & 1) == 0 && (total >> (log_ct + 1)) >= 512) ? 1u : 0u;
     }
+    // latency regime, 32-byte fields: 256-element column tiles run on the register-resident engine (k_stages_col256 & co.)
+    bool col256_ok(unsigned log_ct, unsigned le) const { return sizeof(E) == 32 && log_ct == kLogLowSmall && le < 31 && !col256_off_; }
     static IoDesc<F> io_plain(const E* src, E* dst) {
         IoDesc<F> d{}; d.src = src; d.src_stride = 1; d.src_off = 0; d.ld_mode = LD_PLAIN; d.ld_tbl = nullptr;
         d.dst = dst; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr;
@@ -1967,6 +1981,8 @@ private:
     bool full_cyc_off_ = getenv("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
+    unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
+    bool col256_off_ = getenv("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
     bool row256_off_ = getenv("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };

@@ -1129,6 +1129,28 @@ int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t
     return ok ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
+int ecfft_selftest_blk16_small(const void* matrix256, const void* x, void* out, size_t n, int mode, int device) {
+    if (!matrix256 || !x || !out || !n || n % 256 || mode < 1 || mode > 4) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    Fe256 *dT = nullptr, *dx = nullptr; uint8_t* dA = nullptr;
+    bool ok = hipMalloc(&dT, 256 * sizeof(Fe256)) == hipSuccess && hipMalloc(&dx, n * sizeof(Fe256)) == hipSuccess &&
+              hipMalloc(&dA, Blk16::kABytes + Blk16::kKWords * 8) == hipSuccess;
+    ok = ok && hipMemcpy(dT, matrix256, 256 * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, x, n * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        unsigned long long* dK = reinterpret_cast<unsigned long long*>(dA + Blk16::kABytes);
+        hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, nullptr, dT, dA, dK, false);
+        if (mode == 1) hipLaunchKernelGGL(k_blk16_apply_n16<1>, dim3((unsigned)(n / 256)), dim3(256), 0, nullptr, dx, dA, dK);
+        else if (mode == 2) hipLaunchKernelGGL(k_blk16_apply_n16<2>, dim3((unsigned)(n / 256)), dim3(128), 0, nullptr, dx, dA, dK);
+        else if (mode == 3) hipLaunchKernelGGL(k_blk16_apply_n16<3>, dim3((unsigned)(n / 128)), dim3(128), 0, nullptr, dx, dA, dK);
+        else hipLaunchKernelGGL(k_blk16_apply_n16<4>, dim3((unsigned)(n / 256)), dim3(256), 0, nullptr, dx, dA, dK);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dx, n * sizeof(Fe256), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(dT); (void)hipFree(dx); (void)hipFree(dA);
+    return ok ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);

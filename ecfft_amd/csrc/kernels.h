@@ -1217,6 +1217,103 @@ __device__ __forceinline__ typename F::elem lane_sel(bool c, const typename F::e
     for (int w = 0; w < 8; ++w) r.l[w] = c ? p.l[w] : q.l[w];
     return r;
 }
+// ---------------------------------------------------------------------------------------------
+// Column passes of the LATENCY regime (round 4): 256-element column tiles (2^R rows x C columns), ONE element per thread kept in
+// registers through the R stages — the column-tile counterpart of reg_extend32 / k_stages_row256.  Thread tid holds (row
+// tid >> log_c, column tid & (C - 1)); its partner at stage s' (row distance d = 2^s') is thread tid ^ (d C): eight cross-lane
+// moves when d C < 64, an LDS exchange otherwise.  One multiply per thread per stage (decompose through c0t = np0 dinv), the roles
+// sharing one instruction stream as in reg_extend32.  Same arithmetic, same order as col_stage_sweep: bit-identical.
+// `a`: 256 (or, two vectors per workgroup, 512) elements of LDS for the exchanges.
+// ---------------------------------------------------------------------------------------------
+template <class F, bool DEC>
+__device__ __forceinline__ void reg_col_stages(typename F::elem& x, typename F::elem* a, uint32_t R, uint32_t log_c, uint32_t log_hs, uint32_t c0, uint32_t e,
+                                               const typename F::telem* __restrict__ ta,     // DEC: c0t = np0*dinv | p0
+                                               const typename F::telem* __restrict__ tb,     // DEC: dinv | p1
+                                               uint32_t tid) {
+    using E = typename F::elem;
+    using TE = typename F::telem;
+    static_assert(sizeof(E) == 32, "32-byte fields");
+    const uint32_t cc = tid & ((1u << log_c) - 1), r = tid >> log_c;        // r may carry a vector-select bit above bit R - 1
+    for (uint32_t st = 0; st < R; ++st) {
+        const uint32_t sft = DEC ? R - 1 - st : st, d = 1u << sft, h = d << log_c;
+        const bool hi = (r >> sft) & 1u;
+        const uint32_t ti = (e - 2u * ((1u << log_hs) << sft)) + ((r & (d - 1)) << log_hs) + c0 + cc;
+        const TE t = hi ? ldt(tb, ti) : ldt(ta, ti);
+        E xp;
+        if (h < 64) xp = lane_xor<F>(x, h);
+        else { __syncthreads(); a[tid] = x; __syncthreads(); xp = a[tid ^ h]; }
+        const E A = lane_sel<F>(hi, xp, x), B = lane_sel<F>(hi, x, xp);
+        if (DEC) x = F::tmul_add(t, F::sub(B, A), lane_sel<F>(hi, F::zero(), A));     // lo: a + c0t*(b - a)   hi: dinv*(b - a)
+        else x = F::tmul_add(t, B, A);                                               // a + p*b
+    }
+}
+
+// k_stages_col for 256-element tiles: see reg_col_stages
+template <class F, bool DECOMPOSE>
+__global__ __launch_bounds__(256, 2) void k_stages_col256(IoDesc<F> io, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
+                                                          uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    if constexpr (sizeof(E) == 32) {
+        __shared__ E xch[256];
+        const uint32_t R = kb - ka + 1, tid = threadIdx.x;
+        const uint32_t log_hs = log_e - kb - 1, chunks_log = log_hs - log_c;
+        const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+        const uint32_t c0 = (uint32_t)(chunk << log_c);
+        const size_t pos = (blk << (log_hs + R)) + c0 + ((size_t)(tid >> log_c) << log_hs) + (tid & ((1u << log_c) - 1));
+        E x = io_load<F>(io, pos, ((size_t)1 << log_e) - 1);
+        reg_col_stages<F, DECOMPOSE>(x, xch, R, log_c, log_hs, c0, 1u << log_e, ta, tb, tid);
+        io_store<F>(io, pos, log_e, x);
+    }
+}
+// k_stages_col_mid for 256-element tiles
+template <class F>
+__global__ __launch_bounds__(256, 2) void k_stages_col_mid256(IoDesc<F> io, const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
+                                                              uint32_t log_e, uint32_t ka, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    if constexpr (sizeof(E) == 32) {
+        __shared__ E xch[256];
+        const uint32_t R = kb - ka + 1, tid = threadIdx.x;
+        const uint32_t log_hs = log_e - kb - 1, chunks_log = log_hs - log_c;
+        const size_t blk = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+        const uint32_t c0 = (uint32_t)(chunk << log_c);
+        const size_t pos = (blk << (log_hs + R)) + c0 + ((size_t)(tid >> log_c) << log_hs) + (tid & ((1u << log_c) - 1));
+        E x = io.src[pos];
+        reg_col_stages<F, false>(x, xch, R, log_c, log_hs, c0, 1u << log_e, p0, p1, tid);
+        x = io_mid<F>(io, pos, ((size_t)1 << log_e) - 1, x);
+        reg_col_stages<F, true>(x, xch, R, log_c, log_hs, c0, 1u << log_e, c0t, dinv, tid);
+        io.dst[pos] = F::canon(x);
+    }
+}
+// k_stages_col_enter for 256-element tiles: 512 threads, thread tid < 256 holds the U element, tid >= 256 the V element of the same
+// column position; the combine's odd output w1 U + w1x V is one multiply per thread and an addition
+template <class F>
+__global__ __launch_bounds__(512, 2) void k_stages_col_enter256(const typename F::elem* __restrict__ work, const typename F::elem* __restrict__ src,
+                                                                typename F::elem* __restrict__ dst,
+                                                                const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                                                const typename F::telem* __restrict__ xe, const typename F::telem* __restrict__ w1,
+                                                                const typename F::telem* __restrict__ w1x,
+                                                                uint32_t log_e, uint32_t kb, uint32_t log_c) {
+    using E = typename F::elem;
+    if constexpr (sizeof(E) == 32) {
+        __shared__ E xch[512];
+        const uint32_t R = kb + 1, tid = threadIdx.x;
+        const uint32_t log_hs = log_e - R, chunks_log = log_hs - log_c;
+        const size_t b = (size_t)blockIdx.x >> chunks_log, chunk = (size_t)blockIdx.x & (((size_t)1 << chunks_log) - 1);
+        const uint32_t c0 = (uint32_t)(chunk << log_c);
+        const uint32_t rf = tid >> log_c, v = rf >> R, r = rf & ((1u << R) - 1), cc = tid & ((1u << log_c) - 1);
+        const size_t i = ((size_t)r << log_hs) + c0 + cc, bb = b << (log_e + 1), e = (size_t)1 << log_e;
+        E x = work[bb + ((size_t)v << log_e) + i];
+        reg_col_stages<F, false>(x, xch, R, log_c, log_hs, c0, 1u << log_e, p0, p1, tid);
+        const E y = F::tmul(v ? ldt(w1x, (uint32_t)i) : ldt(w1, (uint32_t)i), x);
+        __syncthreads();
+        xch[tid] = y;
+        __syncthreads();
+        if (v) dst[bb + 2 * i] = F::canon(F::tmul_add(ldt(xe, (uint32_t)i), src[bb + e + i], src[bb + i]));
+        else dst[bb + 2 * i + 1] = F::canon(F::add(xch[tid], xch[tid + 256]));
+    }
+}
+
 template <class F, int BLK>
 __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,

@@ -252,6 +252,11 @@ int ecfft_selftest_field(int field, int op, const void* a, const void* b, const 
  * block of 16 is mapped to out_o = sum_i matrix[o][i] * x_i mod p.  Lets the tests reach the carry-out and canonicalisation
  * branches of the normalisation (identity / -1 / 0 constants, inputs next to 0, p and 2^32 + 977) that a tree's constants never hit. */
 int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t n, int device);
+/* ... the SMALL-LAUNCH forms of the same map (v_mfma_i32_16x16x64_i8; 256-element tiles of the latency regime).
+ * mode 1: 256-element arrays, 4 waves, LDS-resident (k_enter_low<8,256>'s low16)   2: 256-element arrays, 2 waves, two results per
+ * lane (k_exit_low<8,128>'s low16)   3: 128-element arrays = 8 blocks, 2 waves, element in registers (k_exit_low<8,128>'s half-tiles)
+ * 4: 256-element arrays, 4 waves, element in registers (k_stages_row256, k_enter_low<8,256>'s EXTEND cores).  n: a multiple of 256. */
+int ecfft_selftest_blk16_small(const void* matrix256, const void* x, void* out, size_t n, int mode, int device);
 
 /* Measurement hook: field multiplies per second of the butterfly kernels' table multiply run as a bare dependent chain
  * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot

@@ -123,17 +123,25 @@ def test_m31_lazy_table_multiply():
     assert max(d) <= P31 and [v % P31 for v in d] == [(int(x) - int(y)) % P31 for x, y in zip(aa, bb)]
 
 
-def _blk16(T, xs):
-    """ecfft_selftest_blk16: T = 16 x 16 ints, xs = ints (multiple of 1024) -> ints"""
+def _blk16(T, xs, mode=0):
+    """ecfft_selftest_blk16 (mode 0: the 32x32x32 form on 1024-element tiles) / ecfft_selftest_blk16_small (modes 1..4: the
+    16x16x64 forms of the small-launch kernels): T = 16 x 16 ints, xs = ints (multiple of 1024) -> ints"""
     from ecfft_amd import fftree as FT
     m = pack256([T[o][i] for o in range(16) for i in range(16)])
     x = pack256(xs)
     out = np.zeros_like(x)
-    assert FT.lib().ecfft_selftest_blk16(m.ctypes.data, x.ctypes.data, out.ctypes.data, len(xs), 0) == 0
+    if mode == 0:
+        assert FT.lib().ecfft_selftest_blk16(m.ctypes.data, x.ctypes.data, out.ctypes.data, len(xs), 0) == 0
+    else:
+        assert FT.lib().ecfft_selftest_blk16_small(m.ctypes.data, x.ctypes.data, out.ctypes.data, len(xs), mode, 0) == 0
     return unpack256(out)
 
 
-def test_blk16_matrix_core_map_directed():
+BLK16_FORMS = [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("mode", BLK16_FORMS)
+def test_blk16_matrix_core_map_directed(mode):
     """the matrix-core form of the innermost 16-point map (mfma_blk16.h) with explicit constants: identity, -1, 0 and small
     constants put the pre-reduction value next to multiples of 2^256, so the carry-out of the fold and the canonicalisation branch
     of the normalisation run (with a tree's random-looking constants they have probability ~2^-200); results must be canonical"""
@@ -143,16 +151,16 @@ def test_blk16_matrix_core_map_directed():
     xs = (edge * 52)[:1024]
     xs[512:] = [rnd.randrange(P256) for _ in range(512)]
     ident = [[1 if o == i else 0 for i in range(16)] for o in range(16)]
-    assert _blk16(ident, xs) == xs                                            # out = x: every edge value comes back canonical
+    assert _blk16(ident, xs, mode) == xs                                            # out = x: every edge value comes back canonical
     neg = [[P256 - 1 if o == i else 0 for i in range(16)] for o in range(16)]
-    assert _blk16(neg, xs) == [(-v) % P256 for v in xs]
+    assert _blk16(neg, xs, mode) == [(-v) % P256 for v in xs]
     zero = [[0] * 16 for _ in range(16)]
-    assert _blk16(zero, xs) == [0] * 1024
+    assert _blk16(zero, xs, mode) == [0] * 1024
     ones = [[1] * 16 for _ in range(16)]                                       # every output = sum of the block
     want = []
     for b in range(0, 1024, 16):
         want += [sum(xs[b:b + 16]) % P256] * 16
-    assert _blk16(ones, xs) == want
+    assert _blk16(ones, xs, mode) == want
     # constants at the signed-digit recoding threshold and its neighbours, in every position of one row
     thr = 0x7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F
     row = [thr, thr + 1, thr - 1, P256 - thr, 2**255, 2**255 - 1, P256 - 2**255, 255, 256, 2**248, 2**248 - 1, P256 - 256, C, P256 - C, 3, P256 - 3]
@@ -160,10 +168,11 @@ def test_blk16_matrix_core_map_directed():
     want = []
     for b in range(0, 1024, 16):
         want += [sum(Tm[o][i] * xs[b + i] for i in range(16)) % P256 for o in range(16)]
-    assert _blk16(Tm, xs) == want
+    assert _blk16(Tm, xs, mode) == want
 
 
-def test_blk16_matrix_core_map_random_and_targeted_outputs():
+@pytest.mark.parametrize("mode", BLK16_FORMS)
+def test_blk16_matrix_core_map_random_and_targeted_outputs(mode):
     """random 16 x 16 maps against big-int arithmetic, plus inputs solved for so that chosen outputs are exactly 0, 1, p-1 and values
     within 2^40 of 0 and p"""
     rnd = random.Random(12)
@@ -177,7 +186,7 @@ def test_blk16_matrix_core_map_random_and_targeted_outputs():
             b = 16 * k
             rest = sum(Tm[0][i] * xs[b + i] for i in range(1, 16)) % P256
             xs[b] = (tgt - rest) * inv00 % P256
-        got = _blk16(Tm, xs)
+        got = _blk16(Tm, xs, mode)
         want = []
         for b in range(0, 2048, 16):
             want += [sum(Tm[o][i] * xs[b + i] for i in range(16)) % P256 for o in range(16)]

@@ -434,6 +434,56 @@ def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch):
         assert np.array_equal(t_mfma.enter(four, count=4), t_valu.enter(four, count=4))
 
 
+@pytest.mark.parametrize("log_n", [8, 9, 12, 13, 16, 17])
+def test_small_launch_matrix_core_path_equals_valu_paths(gpu, log_n, monkeypatch):
+    """round 4: launches with fewer 1024-element tiles than CUs run on 256-element tiles; their row kernel (k_stages_row256), their
+    column kernels (k_stages_col256 / _mid256 / _enter256) and the low-level kernels keep ONE element per thread in registers, and
+    the stages with pair distance <= 8 — and the four lowest ENTER / EXIT levels — are 16-point maps on v_mfma_i32_16x16x64_i8
+    (mfma_blk16.h, phase_n16).  Three builds of the same library must agree bit for bit: the default, the all-VALU form of the new
+    kernels (ECFFT_NO_MFMA=1), and round 3's generic pair-split kernels (ECFFT_NO_MFMA=1 ECFFT_NO_ROW256=1 ECFFT_NO_COL256=1) —
+    ENTER, EXIT of arbitrary evaluations, EXTEND both ways, the batched forms — on random data and on the byte patterns the operand
+    form (xor 0x80) and the signed-digit matrices are most sensitive to."""
+    n = 1 << log_n
+    P = gpu.FIELDS["secp256k1"]
+    t_new = P.build_fftree(n)
+    monkeypatch.setenv("ECFFT_NO_MFMA", "1")
+    t_valu = P.build_fftree(n)
+    monkeypatch.setenv("ECFFT_NO_ROW256", "1"); monkeypatch.setenv("ECFFT_NO_COL256", "1")
+    t_r3 = P.build_fftree(n)
+    for k in ("ECFFT_NO_MFMA", "ECFFT_NO_ROW256", "ECFFT_NO_COL256"):
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("ECFFT_NO_LOW16", "1")
+    t_nolow = P.build_fftree(n)
+    monkeypatch.delenv("ECFFT_NO_LOW16")
+    rng = np.random.default_rng(0x5EED0416 + log_n)
+    rand = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); rand[:, 3] >>= np.uint64(1)
+    pat = np.zeros((n, 4), dtype=np.uint64)
+    words = np.array([0, 0x8080808080808080, 0x7F7F7F7F7F7F7F7F, 0xFFFFFFFFFFFFFFFF, 0x0101010101010101, 0x00FF00FF00FF00FF, 1, 0x8000000000000000], dtype=np.uint64)
+    for w in range(3):
+        pat[:, w] = words[rng.integers(0, 8, n)]
+    pat[:, 3] = words[rng.integers(0, 8, n)] >> np.uint64(1)                    # < 2^255 < p: canonical
+    pm1 = np.tile(np.array([0xFFFFFFFEFFFFFC2E, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64), (n, 1))   # p - 1 everywhere
+    cols = np.zeros((n, 4), dtype=np.uint64)
+    pos = np.arange(n)
+    sel = (pos % 16) == ((pos // 16) % 16)                                       # block b carries its value in position b mod 16
+    cols[sel] = rand[sel]
+    for data in (rand, pat, pm1, cols):
+        ev = t_new.enter(data)
+        for other in (t_valu, t_r3, t_nolow):
+            assert np.array_equal(ev, other.enter(data))
+            assert np.array_equal(t_new.exit(data), other.exit(data))
+        assert np.array_equal(t_new.exit(ev), data)
+        h = data[: n // 2]
+        for m in (gpu.Moiety.S1, gpu.Moiety.S0):
+            assert np.array_equal(t_new.extend(h, m), t_r3.extend(h, m))
+    if log_n >= 12:
+        for cnt in (2, 8):                                                       # batched forms: count polynomials of n / count per launch
+            assert np.array_equal(t_new.enter(rand, count=cnt), t_r3.enter(rand, count=cnt))
+            assert np.array_equal(t_new.exit(rand, count=cnt), t_r3.exit(rand, count=cnt))
+        e = n // 64                                                              # many short vectors per EXTEND launch
+        assert np.array_equal(t_new.extend(rand[: n // 2], gpu.Moiety.S1, count=(n // 2) // e), t_r3.extend(rand[: n // 2], gpu.Moiety.S1, count=(n // 2) // e))
+
+
 def test_low16_maps_equal_the_level_code(gpu, monkeypatch):
     """round 3: in the 1024-element low-level kernels the four lowest ENTER / EXIT levels of every 16-block are ONE matrix-core map
     each (DeviceChain::build_low16: images of the unit vectors under the level code itself).  ECFFT_NO_LOW16=1 keeps every other
