@@ -312,8 +312,16 @@ def main():
         def watchdog():
             if finished.wait(limit):
                 return
+            # a peer is gone or stuck: ncclCommAbort on this rank's communicator(s) (ecfft_comm_abort) makes the blocked sharded call
+            # return an error, so the process leaves through the ordinary path below with split.status = 1 — every rank has the same
+            # watchdog, so nobody is left for torchrun to reap.  Only when that fails too (callback transport) the process is ended.
+            split_obj["error"] = f"the split part did not finish within {limit:.0f} s (ECFFT_SPLIT_TIMEOUT_S); replica line kept"
+            split_obj["status"] = 1
+            aborted = [c.abort() for c in list(_LIVE_COMMS)]
+            split_obj["communicators_aborted"] = sum(1 for a in aborted if a)
+            if any(aborted) and finished.wait(45):
+                return
             if rank == 0:
-                split_obj["error"] = f"the split part did not finish within {limit:.0f} s (ECFFT_SPLIT_TIMEOUT_S); replica line kept"
                 out["split"] = split_obj
                 print(json.dumps(out), flush=True)
             os._exit(0)
@@ -324,13 +332,13 @@ def main():
                 split_obj["enter_exit"] = enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_n)
             if args.split_log_e:
                 split_obj["extend"] = extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev, args.split_log_e)
-        except Exception as ex:  # a rank that fails here leaves its peers in a collective: the watchdog ends those
-            split_obj["error"] = f"{type(ex).__name__}: {ex}"
-            if rank == 0:
-                out["split"] = split_obj
-                print(json.dumps(out), flush=True)
+        except Exception as ex:  # a rank that fails here leaves its peers in an exchange: their watchdogs abort those
+            split_obj.setdefault("error", f"{type(ex).__name__}: {ex}")
+            split_obj["status"] = 1
             sys.stderr.write(f"bench.py rank {rank}: split part failed: {split_obj['error']}\n")
-            os._exit(0)
+            for c in list(_LIVE_COMMS):
+                c.abort()                        # nothing of this rank may sit in an exchange when the process group is torn down
+        split_obj.setdefault("status", 0)
         finished.set()
         if rank == 0:
             out["split"] = split_obj              # N = 1 lines carry no such key (byte-compatible with earlier rounds)
@@ -350,17 +358,26 @@ def main():
         dist.destroy_process_group()
 
 
+_LIVE_COMMS = []          # communicators of the split part: the watchdog aborts them when the part is stuck
+
+
 def _make_comm(D, dist, world):
     """RCCL communicator (one rank per GPU); ECFFT_BENCH_BACKEND=gloo -> host-staged callback transport (functional test only)"""
-    if os.environ.get("ECFFT_BENCH_BACKEND", "nccl") == "nccl":
-        return D.Comm.rccl()
-    return D.Comm.callback()
+    c = D.Comm.rccl() if os.environ.get("ECFFT_BENCH_BACKEND", "nccl") == "nccl" else D.Comm.callback()
+    _LIVE_COMMS.append(c)
+    return c
 
 
 def _split_report(comm, steps):
     st = comm.stats()
-    return {"comm_ms_per_step": st["comm_ms"] / max(steps, 1), "exchanges_per_step": st["exchanges"] / max(steps, 1),
-            "bytes_sent_per_step_per_rank": st["bytes_sent"] / max(steps, 1)}
+    rep = {"comm_ms_per_step": st["comm_ms"] / max(steps, 1), "exchanges_per_step": st["exchanges"] / max(steps, 1),
+           "bytes_sent_per_step_per_rank": st["bytes_sent"] / max(steps, 1)}
+    if comm.world == 1:
+        # one rank: every "exchange" is a device-to-device copy of the rank's own chunk through the transport — not communication
+        rep["self_copy_ms_per_step"] = rep["comm_ms_per_step"]
+        rep["comm_ms_per_step"] = 0.0
+        rep["note"] = "world = 1: the exchanges are self send / receives; their time is self_copy_ms_per_step, no inter-GPU communication is measured"
+    return rep
 
 
 def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda", log_e=None):
@@ -410,7 +427,7 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
     barrier(); inst = time.perf_counter() - t1
     phases = _split_report(comm, args.steps)
     phases["instrumented_ms_per_step"] = inst * 1e3 / max(args.steps, 1)
-    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"]
+    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"] - phases.get("self_copy_ms_per_step", 0.0)
     comm.stats(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
@@ -480,7 +497,7 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     barrier(); inst = time.perf_counter() - t1
     phases = _split_report(comm, args.steps)
     phases["instrumented_ms_per_step"] = inst * 1e3 / max(args.steps, 1)
-    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"]
+    phases["compute_ms_per_step"] = phases["instrumented_ms_per_step"] - phases["comm_ms_per_step"] - phases.get("self_copy_ms_per_step", 0.0)
     comm.stats(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); elapsed = float(tt.item())
@@ -518,6 +535,11 @@ INSTR_PER_MUL = {"secp256k1": 169, "m31": 6}     # VALU instructions of the kern
 N_SIMD = 256 * 4
 
 
+# environment switches that change which kernels / code paths run (A/B tools): the committed PMC counters do not apply then
+AB_SWITCHES = ("ECFFT_NO_MFMA", "ECFFT_NO_LOW16", "ECFFT_NO_FULL_CYCLIC", "ECFFT_NO_SMALL_TILES", "ECFFT_NO_ROW256", "ECFFT_NO_COL256",
+               "ECFFT_SMALL_MIN_LOGC", "ECFFT_LIB")
+
+
 def _counters(field, log_n):
     """per-class rocprofv3 counters of this workload from the newest committed PMC pass (profiles/r*/counters_<field>_<log n>.json,
     produced by tools/prof_counters.sh), else None"""
@@ -546,6 +568,11 @@ def build_roofline(args, F, n, classes, step_s, device):
         return None
     dom = max(live, key=lambda c: c["ms"])
     ctr, src = _counters(args.field, args.log_n)
+    # the committed counters describe the DEFAULT build and code path: with an A/B switch set (or another library) they belong to
+    # other kernels than the ones this run times, so every counter-derived field stays empty instead of mixing epochs
+    switches = [k for k in AB_SWITCHES if os.environ.get(k)]
+    if switches:
+        ctr, src = None, None
     cls_ctr = (ctr or {}).get("classes", {})
     per_class = []
     tot_bytes = tot_insts = 0.0
@@ -591,7 +618,7 @@ def build_roofline(args, F, n, classes, step_s, device):
                          "alg_bytes_check": {"profiler_sum_per_step": sum(c["alg_bytes"] for c in live) / args.steps, "closed_form": be + bx},
                          "note": "ALGORITHMIC bytes of the stage-streaming model (SURVEY 8(d)) / measured time; >= 10 stages share one HBM "
                                  "round trip in the fused kernels, so this can exceed the HBM line and is not a fraction of it"},
-           "per_class": per_class, "counters_source": src,
+           "per_class": per_class, "counters_source": src, "counters_skipped_for_switches": switches or None,
            "note": "achieved / frac / traffic: HBM bytes really moved per launch of the dominant kernel (rocprofv3 PMC, committed under "
                    "profiles/) over its launch time measured in this run with HIP events; achieved_alg / frac_alg: the same launch time under "
                    "SURVEY 8(d)'s algorithmic bytes; counters_stale = the PMC pass was taken from other kernel sources than the ones running"}
@@ -613,6 +640,9 @@ def build_roofline(args, F, n, classes, step_s, device):
                        "note": "peak = ecfft_mul_ceiling: the kernels' OWN 169-instruction table multiply as a bare dependent chain on the whole "
                                "chip (8 workgroups per CU requested; the 94-VGPR chain fits 5 waves per SIMD) - a ceiling of this "
                                "implementation's multiply, not of the machine: see valu_machine for the instruction-issue utilisation"}
+        if switches:     # no counters for this code path: how the multiplies split between the pipes is not known
+            out["valu"].update({"of_which_on_matrix_cores": None, "valu_mul_per_step": None, "achieved": None, "frac": None,
+                                "note": out["valu"]["note"] + "; counter-derived fields are empty: " + ", ".join(switches) + " set"})
         if tot_insts:
             ipm = INSTR_PER_MUL[args.field]
             floor = clock_mhz * 1e6 * N_SIMD * 64 / (max(ceil4, ceil8) * ipm)     # cycles per wave-instruction per SIMD of the bare chain
@@ -648,8 +678,10 @@ def build_roofline(args, F, n, classes, step_s, device):
                             "hbm_bytes_per_step": tot_bytes, "traffic_over_compulsory": tot_bytes / comp}
     # what binds: the larger of the two measured fractions
     hb = (out.get("whole_job") or {}).get("hbm_frac") or out.get("frac") or 0.0
-    vb = max((out.get("valu_issue") or {}).get("frac", 0.0), (out.get("valu") or {}).get("frac", 0.0))
+    vb = max((out.get("valu_issue") or {}).get("frac") or 0.0, (out.get("valu") or {}).get("frac") or 0.0)
     out["bound"] = "valu" if vb >= hb else "hbm"
+    if switches:
+        out["bound"] = None                     # no counters for this code path: nothing measured decides it
     out["bound_evidence"] = {"hbm_frac_of_8TBs": hb, "valu_frac_of_multiply_chain": vb}
     return out
 

@@ -312,6 +312,8 @@ impl<F: HipField> HipFFTree<F> {
     /// `CanonicalDeserialize::deserialize_compressed / deserialize_uncompressed` (src/fftree.rs:600-660): a file written by the crate
     /// (`README.md:26-41` build.rs flow) becomes a device-resident tree.  `verify`: compare every table of the file with the one
     /// recomputed from its point set and reject the file (`None`) on a mismatch; malformed input is `None` as well.
+    /// Prefer [`Self::deserialize_checked`]: with `verify = false` only the layers of `f` are checked and every other table is
+    /// recomputed from the point set, whereas the reference would use the file's tables verbatim.
     pub fn deserialize(bytes: &[u8], compress: ark_serialize::Compress, device: i32, verify: bool) -> Option<Self> {
         let c = matches!(compress, ark_serialize::Compress::Yes) as i32;
         let mut ctx = core::ptr::null_mut();
@@ -322,6 +324,10 @@ impl<F: HipField> HipFFTree<F> {
                 Some(Self { ctx, _f: PhantomData })
             }
         }
+    }
+    /// `deserialize` with every table of the file verified against the tree rebuilt from its point set (the safe default)
+    pub fn deserialize_checked(bytes: &[u8], compress: ark_serialize::Compress, device: i32) -> Option<Self> {
+        Self::deserialize(bytes, compress, device, true)
     }
     /// the `pub rational_maps` field (src/fftree.rs:28) as (numerator, denominator) coefficient triples, low -> high, zero padded
     pub fn rational_maps(&self) -> Vec<([F; 3], [F; 3])> {

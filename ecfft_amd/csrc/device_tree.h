@@ -20,6 +20,7 @@
 #include <set>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -114,6 +115,9 @@ public:
     const HostTree<F>& host() const { return host_; }
     const E* f_device() const { return f_; }
     std::mutex& lock() { return mu_; }
+    // test hook, process wide: the rank whose local part of the next collective ecfft_build_exit_shard reports failure (-1: none).
+    // Set through the ABI only (ecfft_test_fail_build_rank) — no environment variable can reach it.
+    static std::atomic<int>& test_fail_build_rank() { static std::atomic<int> r{-1}; return r; }
     Profiler& profiler() const { return prof_; }
 
     // ------------------------------------------------------------------------------------------
@@ -176,7 +180,9 @@ public:
     // and the host-call staging buffer come and go)
     size_t device_bytes() const { return (arena_cap_ + scratch_cap_) * sizeof(E) + pool_bytes() + full_cyc_bytes_; }
     // ecfft_ctx_trim: give every idle pooled temporary back to the device (between calls; takes the context lock)
-    void trim() { std::lock_guard<std::mutex> g(mu_); temps_trim(0); (void)hipDeviceSynchronize(); full_cyclic_free(); }
+    // `also`: runs under the same lock (the ABI layer frees its host-call staging buffer there: run_op / run_alg use it under lock())
+    template <class Fn>
+    void trim(Fn&& also) { std::lock_guard<std::mutex> g(mu_); temps_trim(0); (void)hipDeviceSynchronize(); full_cyclic_free(); also(); }
     enum { kShardNone = 0, kShardExtend = 1, kShardEnter = 2, kShardExit = 3 };
     int shard_kind() const { return shard_kind_; }
     bool shard_mode() const { return shard_kind_ != kShardNone; }
@@ -580,7 +586,7 @@ public:
         };
         bool local_ok = local_part();
         fail_next_collective_ = false;
-        if (const char* fr = getenv("ECFFT_TEST_FAIL_BUILD_RANK")) { if ((unsigned)atoi(fr) == rank) local_ok = false; }   // test hook: this rank's local part "fails"
+        if (test_fail_build_rank().load() == (int)rank) local_ok = false;   // test hook (ecfft_test_fail_build_rank): this rank's local part "fails"
         if (!tr.vote(local_ok, s)) { fprintf(stderr, "ecfft: sharded EXIT build: the local part failed on %s rank\n", local_ok ? "another" : "this"); return false; }
         shard_kind_ = kShardExit; shard_log_p_ = log_p; shard_rank_ = rank;      // extend_split must read the shares from here on
         const E* f = fdev; const size_t N = N_;
@@ -1097,13 +1103,15 @@ public:
         try { alloc(); } catch (const DeviceAllocError&) { local_ok = false; }
         if (fail_next_collective_) { local_ok = false; fail_next_collective_ = false; }        // test hook
         const uint64_t key = ((uint64_t)op << 60) | ((uint64_t)variant << 56) | ((uint64_t)(unsigned)tr.world << 48) | (uint64_t)len;
-        if (agreed_shapes_.count(key)) return local_ok;
+        // an agreed shape cannot fail locally (its temporaries are pinned) — unless the test hook says so: then the ranks vote
+        // again, so that the peers that passed do not walk into the exchanges alone
+        if (agreed_shapes_.count(key) && local_ok) return true;
         if (!tr.vote(local_ok, s)) { temps_done(); return false; }
         agreed_shapes_.insert(key);
         for (auto& b : pool_) if (b.busy) b.pinned = true;
         return true;
     }
-    void test_fail_next_collective() { fail_next_collective_ = true; }
+    void test_fail_next_collective() { std::lock_guard<std::mutex> g(mu_); fail_next_collective_ = true; }
     bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s, bool cyc_in = false, bool cyc_out = false) {
         const size_t P = (size_t)tr.world, c = e / P;
         if (P & (P - 1)) return false;

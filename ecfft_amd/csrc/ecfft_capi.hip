@@ -640,13 +640,15 @@ int wire_read(int field, const uint8_t* data, size_t len, int compress, int devi
     c->field = field; c->device = device;
     int rc = guarded([&] { return finish_build(std::move(ht), device, (*c).*slot); });
     if (rc != ECFFT_OK) return rc;
-    if (verify) {
+    {   // verify == 0 still checks the internal layers of every `f` (they follow from the leaves and the maps: cheap, and a file
+        // whose layers disagree with its maps would otherwise load as a different tree than the reference's deserialize builds)
         DeviceGuard dev(device);
         if (!dev.ok) return ECFFT_ERR_HIP;
         DeviceChain<F>& ch = *((*c).*slot);
         std::vector<E> got;
         for (const WireLevel& lv : levels)
             for (int which = 0; which < 11; ++which) {
+                if (!verify && which != ECFFT_TBL_F) continue;
                 if (!lv.tbl[which] && lv.cnt[which] == 0) continue;
                 got.resize(lv.cnt[which] ? lv.cnt[which] : 1);
                 rc = guarded([&] { return table_of(ch, lv.n, which, got.data(), lv.cnt[which], nullptr, true); });
@@ -852,12 +854,18 @@ int ecfft_test_fail_next_collective(ecfft_ctx* ctx) {
     if (ctx->field == ECFFT_FIELD_SECP256K1) ctx->secp->test_fail_next_collective(); else ctx->m31->test_fail_next_collective();
     return ECFFT_OK;
 }
+int ecfft_test_fail_build_rank(int rank) {
+    DeviceChain<Secp256k1>::test_fail_build_rank().store(rank);
+    DeviceChain<M31>::test_fail_build_rank().store(rank);
+    return ECFFT_OK;
+}
 int ecfft_ctx_trim(ecfft_ctx* ctx) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     DeviceGuard dev(ctx->device);
     if (!dev.ok) return ECFFT_ERR_HIP;
-    if (ctx->field == ECFFT_FIELD_SECP256K1) ctx->secp->trim(); else ctx->m31->trim();
-    if (ctx->stage) { (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+    // the staging buffer is used under the chain lock by every host-memory call: it is freed under that lock too
+    auto free_stage = [ctx] { if (ctx->stage) { (void)hipFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; } };
+    if (ctx->field == ECFFT_FIELD_SECP256K1) ctx->secp->trim(free_stage); else ctx->m31->trim(free_stage);
     return ECFFT_OK;
 }
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx) {
@@ -963,6 +971,10 @@ void ecfft_comm_destroy(ecfft_comm* comm) {
     if (!comm) return;
     DeviceGuard dev(comm->t ? comm->t->device : 0);
     delete comm;
+}
+int ecfft_comm_abort(ecfft_comm* comm) {
+    if (!comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    return comm->t->abort() ? ECFFT_OK : ECFFT_ERR_HIP;            // callable from another host thread than the one that is blocked
 }
 int ecfft_comm_rank(const ecfft_comm* comm) { return comm && comm->t ? comm->t->rank : -1; }
 int ecfft_comm_world(const ecfft_comm* comm) { return comm && comm->t ? comm->t->world : 0; }

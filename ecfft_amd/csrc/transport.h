@@ -24,6 +24,9 @@ class Transport {
 public:
     virtual ~Transport() { for (hipEvent_t e : ev_) (void)hipEventDestroy(e); if (vote_dev_) (void)hipFree(vote_dev_); }
     int rank = 0, world = 1, device = 0;
+    // unblocks every exchange in flight and makes the later ones fail (ncclCommAbort): for a caller whose peer is gone.  The
+    // communicator can only be destroyed afterwards.  Default: nothing to abort (the callback transport belongs to the host).
+    virtual bool abort() { return false; }
     // every send and receive of the call progresses together (ncclGroupStart / ncclGroupEnd semantics); messages between one
     // pair of ranks match in the order given; buffers are device memory; the work is enqueued on `s`
     bool exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) {
@@ -83,6 +86,7 @@ struct RcclApi {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommAbort)(Comm) = nullptr;                    // optional
     int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -100,12 +104,19 @@ private:
         RcclApi a;
         // reuse the copy that is already mapped (PyTorch-ROCm bundles its own librccl and has it loaded), else the system one
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (a.handle) break; }
+        // ECFFT_RCCL_LIB: an explicit library instead (a differently named RCCL build; the tests' stand-in that lets several ranks
+        // share one GPU, tests/stub_rccl) — bound with RTLD_LOCAL so that its symbols do not shadow a librccl that is already mapped
+        if (const char* ovr = getenv("ECFFT_RCCL_LIB")) {
+            a.handle = dlopen(ovr, RTLD_NOW | RTLD_LOCAL);
+            if (!a.handle) { fprintf(stderr, "ecfft: ECFFT_RCCL_LIB=%s could not be loaded (%s)\n", ovr, dlerror()); return a; }
+        }
+        if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (a.handle) break; }
         if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) break; }
         if (!a.handle) { fprintf(stderr, "ecfft: librccl.so not found (%s)\n", dlerror()); return a; }
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+        a.CommAbort = (decltype(a.CommAbort))dlsym(a.handle, "ncclCommAbort");
         a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
         a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
         a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
@@ -118,6 +129,12 @@ private:
 class RcclTransport : public Transport {
 public:
     ~RcclTransport() override { if (comm_) (void)RcclApi::get().CommDestroy(comm_); }
+    bool abort() override {
+        RcclApi& api = RcclApi::get();
+        if (!comm_ || !api.CommAbort) return false;
+        aborted_ = true;
+        return api.CommAbort(comm_) == 0;
+    }
     bool init(const void* id128, int world_, int rank_, int device_) {
         RcclApi& api = RcclApi::get();
         if (!api.ok()) return false;
@@ -130,6 +147,7 @@ public:
 protected:
     bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
         RcclApi& api = RcclApi::get();
+        if (aborted_) return false;
         const int kChar = 0;                              // ncclChar / ncclInt8
         int rc = api.GroupStart();
         for (int i = 0; i < ns && rc == 0; ++i) rc = api.Send(sends[i].ptr, sends[i].bytes, kChar, sends[i].peer, comm_, s);
@@ -141,6 +159,7 @@ protected:
     }
 private:
     RcclApi::Comm comm_ = nullptr;
+    bool aborted_ = false;
 };
 
 class CallbackTransport : public Transport {

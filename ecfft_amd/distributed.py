@@ -140,6 +140,14 @@ class Comm:
         fftree._check(L.ecfft_comm_init_callback(world, rank, device, cb, None, ctypes.byref(h)))
         return Comm(h, keep=cb)
 
+    def abort(self):
+        """ncclCommAbort (RCCL transports): unblocks exchanges in flight; later sharded calls on this communicator fail.  Returns
+        False for a callback transport.  May be called from another thread than the blocked one."""
+        from . import fftree
+        L = fftree.lib()
+        L.ecfft_comm_abort.restype, L.ecfft_comm_abort.argtypes = ctypes.c_int, [ctypes.c_void_p]
+        return L.ecfft_comm_abort(self._h) == 0
+
     def stats(self, enable=None):
         """enable=True/False switches per-exchange timing on / off; enable=None reads {comm_ms, exchanges, bytes_sent} and resets"""
         from . import fftree

@@ -83,7 +83,8 @@ long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m);
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch + pooled temporaries (+ gathered cyclic tables) */
 /* The algorithm wrappers (ecfft_redc, ecfft_vanish, ecfft_degree, the sharded transforms ...) keep their temporaries in a
  * per-context pool between calls; the pool is capped (idle blocks beyond twice the transform scratch are freed at the end of a
- * call) and this call returns ALL idle blocks and the host-call staging buffer to the device.  Call between transforms.
+ * call) and this call returns every idle block — except the pinned temporaries of sharded call shapes the ranks have agreed on, which
+ * stay so that those calls keep running without allocation — and the host-call staging buffer to the device.  Call between transforms.
  * A full context that has served sharded EXTENDs also holds compact copies of the cyclic stages' table entries (gathered on
  * first use, counted by ecfft_ctx_device_bytes); they are returned too and gathered again when needed. */
 int ecfft_ctx_trim(ecfft_ctx* ctx);
@@ -147,6 +148,11 @@ int ecfft_comm_get_unique_id(void* id_out);                                     
 int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out);
 int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn fn, void* user, ecfft_comm** out);
 void ecfft_comm_destroy(ecfft_comm* comm);
+/* RCCL transports: ncclCommAbort — unblocks the exchanges in flight (a peer died or never arrived) and makes every later sharded
+ * call on this communicator return ECFFT_ERR_HIP; may be called from another host thread than the blocked one.  ECFFT_ERR_HIP for a
+ * callback transport (the host owns its exchanges).  The librccl that is bound can be chosen with the environment variable
+ * ECFFT_RCCL_LIB (default: the copy already mapped into the process, else /opt/rocm/lib/librccl.so). */
+int ecfft_comm_abort(ecfft_comm* comm);
 int ecfft_comm_rank(const ecfft_comm* comm);
 int ecfft_comm_world(const ecfft_comm* comm);
 /* communication time: while enabled every exchange is bracketed by HIP events on its stream; _read synchronises the device */
@@ -190,6 +196,8 @@ int ecfft_extend_sharded_layout(ecfft_ctx* ctx, ecfft_comm* comm, const void* in
  * after its local part, at every level and on its final status.  ecfft_test_fail_next_collective (test hook) makes the local
  * preparation of the context's next such call report failure. */
 int ecfft_test_fail_next_collective(ecfft_ctx* ctx);
+/* test hook, process wide: the local part of the next collective ecfft_build_exit_shard reports failure on rank `rank` (-1: off) */
+int ecfft_test_fail_build_rank(int rank);
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 
@@ -213,7 +221,10 @@ int ecfft_tree_table(ecfft_ctx* ctx, size_t m, int which, void* host_out, size_t
  *   ecfft_fftree_deserialize <-> FFTree::deserialize_compressed / deserialize_uncompressed (:600-660): bounds-checked parse (a
  *       truncated, non-canonical or inconsistent file is ECFFT_ERR_BAD_ARG), then FFTree::new on the file's leaves and maps —
  *       every other table is recomputed on the GPU.  verify != 0 compares each table of the file with the recomputed one and
- *       rejects the file on a mismatch (the reference trusts the file: Valid::check is a no-op, :592-597). */
+ *       rejects the file on a mismatch (the reference trusts the file: Valid::check is a no-op, :592-597).  verify == 0 still checks the
+ *       internal layers of `f`; the file's OTHER tables are then neither used nor checked — a file whose tables disagree with its
+ *       point set loads as the tree of its point set, where the reference would use the file's tables verbatim.  Bindings should
+ *       default to verify = 1. */
 int ecfft_fftree_serialize(ecfft_ctx* ctx, int compress, void* buf, size_t cap, size_t* len);
 /* the pub field rational_maps (src/fftree.rs:28) of the top tree: log2(n) maps, 3 numerator + 3 denominator coefficients each
  * (low -> high, zero padded), element representation as everywhere; either output may be NULL */

@@ -29,8 +29,16 @@ def synth(field, n, seed):
 
 def main():
     # ECFFT_WORKER_RCCL=1 (multi-GPU hosts): one rank per GPU, exchanges over the real RCCL transport (grouped ncclSend / ncclRecv)
+    # ECFFT_WORKER_RCCL=stub (one-GPU hosts): every rank on cuda:0, gloo for the process group, and the RcclTransport bound to the
+    # test-only stand-in library (ECFFT_RCCL_LIB = tests/stub_rccl/librccl_stub.so): the RCCL code path with world > 1
+    stub = os.environ.get("ECFFT_WORKER_RCCL") == "stub"
     rccl = os.environ.get("ECFFT_WORKER_RCCL") == "1"
-    if rccl:
+    if stub:
+        assert os.environ.get("ECFFT_RCCL_LIB"), "stub mode needs ECFFT_RCCL_LIB"
+        dev = 0
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
+    elif rccl:
         dev = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -40,7 +48,7 @@ def main():
         torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
     ok = True
-    comm = D.Comm.rccl(device=dev) if rccl else D.Comm.callback()
+    comm = D.Comm.rccl(device=dev) if (rccl or stub) else D.Comm.callback()
     assert comm.rank == rank and comm.world == world
     for field, n in (("secp256k1", 1 << 13), ("m31", 1 << 16)):
         F = ecfft_amd.FIELDS[field]

@@ -25,6 +25,19 @@ def test_closed_forms_match_survey():
     assert we == pytest.approx(1.89e10, rel=5e-3)                        # config 5
 
 
+def test_ab_switches_empty_the_counter_derived_fields(monkeypatch):
+    """VERDICT r03 evidence hygiene: the committed PMC counters describe the default code path; with an A/B switch in the
+    environment the line must not carry counter-derived numbers of other kernels (mixed epochs with counters_stale = false)"""
+    monkeypatch.setenv("ECFFT_NO_MFMA", "1")
+    args = types.SimpleNamespace(field="secp256k1", log_n=20, steps=10)
+    r = bench.build_roofline(args, _FakeField(), 1 << 20, _classes(), 8.4e-3, 0)
+    assert r["counters_skipped_for_switches"] == ["ECFFT_NO_MFMA"] and r["counters_source"] is None and r["counters_stale"] is False
+    assert r["achieved"] is None and r["frac"] is None and r["traffic"] is None
+    assert r["valu"]["of_which_on_matrix_cores"] is None and r["valu"]["frac"] is None and "valu_issue" not in r
+    assert all("hbm_bytes_per_launch" not in c and "valu_insts_per_launch" not in c for c in r["per_class"])
+    assert r["frac_alg"] > 0                                              # the event-time figures stay
+
+
 class _FakeField:
     elem_bytes = 32
 

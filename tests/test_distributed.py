@@ -54,6 +54,38 @@ def test_sharded_transforms_over_rccl_multi_gpu():
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def _stub_rccl():
+    """tests/stub_rccl/librccl_stub.so (built by __graft_entry__.build(); rebuilt here if missing)"""
+    lib = os.path.join(ROOT, "tests", "stub_rccl", "librccl_stub.so")
+    if not os.path.exists(lib):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", lib, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp"), "-lrt"], check=True)
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_transport_with_several_ranks_through_the_stub_library(world):
+    """round 4: the RcclTransport code path (grouped ncclSend / ncclRecv with several peers per group, sub-group peer lists of the
+    split ENTER / EXIT levels, Transport::vote, the collective ecfft_build_exit_shard) with world = 2 and 4 on ONE GPU: librccl is
+    replaced by a test-only stand-in (tests/stub_rccl: the entry points transport.h binds, bytes staged through POSIX shared
+    memory between the processes) selected with ECFFT_RCCL_LIB.  Same worker and checks as the real multi-GPU test."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ECFFT_WORKER_RCCL="stub", ECFFT_RCCL_LIB=_stub_rccl())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_comm_abort_unblocks_a_rank_whose_peer_never_arrives():
+    """ecfft_comm_abort (ncclCommAbort): rank 0 of a two-rank communicator starts a split EXTEND whose peer never makes the call; a
+    second host thread aborts the communicator and the blocked call returns an error instead of hanging (stub library: the peer
+    process attaches and then just sleeps; tests/abort_worker.py)."""
+    env = dict(os.environ, ECFFT_RCCL_LIB=_stub_rccl(), ECFFT_STUB_RCCL_TIMEOUT_S="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abort_worker.py"), "main"], env=env, capture_output=True, text=True, timeout=300)
+    assert "RETURNED_ERROR" in r.stdout and "abort -> True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 def test_rccl_worker_with_one_rank():
     """the multi-GPU worker in its RCCL mode (nccl process group, Comm.rccl) with world = 1: keeps the script the multi-GPU test
@@ -447,7 +479,7 @@ def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(mon
     import ecfft_amd
     from ecfft_amd import fftree as FT
     F = ecfft_amd.FIELDS["m31"]
-    monkeypatch.setenv("ECFFT_TEST_FAIL_BUILD_RANK", "1")
+    assert FT.lib().ecfft_test_fail_build_rank(1) == 0        # set through the ABI: no environment variable reaches the hook
     res = {}
 
     def body(rank, make_comm):
@@ -459,6 +491,6 @@ def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(mon
 
     _thread_ranks(2, body)
     assert res == {0: "error", 1: "error"}, res
-    monkeypatch.delenv("ECFFT_TEST_FAIL_BUILD_RANK")
+    assert FT.lib().ecfft_test_fail_build_rank(-1) == 0
     _thread_ranks(2, lambda rank, make_comm: res.__setitem__(rank, F.build_exit_shard(1 << 12, make_comm()) is not None))
     assert res == {0: True, 1: True}

@@ -80,6 +80,14 @@ def test_c_deserializer_rejects_bad_files(oracle_tree, field):
     with pytest.raises(ValueError):
         S.deserialize_fftree(P, bytes(tampered), False, verify=True)
     assert S.deserialize_fftree(P, bytes(tampered), False, verify=False).n == 16     # the reference trusts the file too (Valid::check is a no-op)
+    # an INTERNAL layer of f (heap entry 3: layer with 2 points) that disagrees with the leaves and maps is refused even without
+    # verify — the f layers are always checked; a file whose f length is not a power of two is a ValueError too
+    layer = bytearray(data); layer[8 + 3 * eb] ^= 1
+    with pytest.raises(ValueError):
+        S.deserialize_fftree(P, bytes(layer), False, verify=False)
+    notpow2 = bytearray(data); notpow2[0:8] = (24).to_bytes(8, "little")
+    with pytest.raises(ValueError):
+        S.deserialize_fftree(P, bytes(notpow2), False)
     # compressed files carry no inverse tables; the loaded tree has them (regenerated, src/fftree.rs:620-628)
     t = S.deserialize_fftree(P, S.serialize_fftree(ot, P, True), True)
     assert np.array_equal(t.table(S.T_XNN_S_INV, 16), ot.table(S.T_XNN_S_INV, 16))
