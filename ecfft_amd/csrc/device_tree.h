@@ -299,7 +299,8 @@ public:
                     if (only_target >= 0 && sg != 1 - only_target) continue;
                     uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
                     unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
-                    hipLaunchKernelGGL(k_blk16_build, dim3(1), dim3(256), 0, s, T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], e, A, K);
+                    const Blk16BuildArgs ba{T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], A, K};
+                    hipLaunchKernelGGL(k_blk16_build, dim3(1), dim3(256), 0, s, ba, ba, e);
                     T.blk16_A[sg] = A; T.blk16_K[sg] = K;
                 }
             }
@@ -1753,12 +1754,14 @@ private:
         T.blk16_A[0] = T.blk16_A[1] = nullptr; T.blk16_K[0] = T.blk16_K[1] = nullptr;
         if constexpr (sizeof(E) == 32) {
             if (T.e < 16 || mfma_off_) return;
+            Blk16BuildArgs ba[2];
             for (int sg = 0; sg < 2; ++sg) {
                 uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems));
                 unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
-                hipLaunchKernelGGL(k_blk16_build, dim3(1), dim3(256), 0, s, T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], T.e, A, K);
+                ba[sg] = {T.np0[sg], T.dinv[sg], T.p0[1 - sg], T.p1[1 - sg], T.inner[sg], A, K};
                 T.blk16_A[sg] = A; T.blk16_K[sg] = K;
             }
+            hipLaunchKernelGGL(k_blk16_build, dim3(2), dim3(256), 0, s, ba[0], ba[1], T.e);       // both source parities in one launch
         }
     }
 

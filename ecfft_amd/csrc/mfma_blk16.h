@@ -433,41 +433,42 @@ struct Blk16 {
 __device__ __forceinline__ void blk16_expand(Fe256* Tm, Fe256* csum, uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc, uint32_t tid);
 
 // np0 / dinv: decompose tables of the source parity, p0 / p1: recombine tables of the target parity, inner: merged innermost
-// pair (all as the row kernel receives them), e = vector length of the tree (>= 16)
-__global__ __launch_bounds__(256) void k_blk16_build(const Te256* __restrict__ np0, const Te256* __restrict__ dinv, const Te256* __restrict__ p0,
-                                                     const Te256* __restrict__ p1, const Te256* __restrict__ inner, size_t e,
-                                                     uint8_t* __restrict__ Amat, unsigned long long* __restrict__ Kc) {
+// pair (all as the row kernel receives them), e = vector length of the tree (>= 16).  grid = 2: block sg builds the map of source
+// parity sg.  The unit-vector pass is spread over the workgroup (round 4; it was 16 serial threads with a 16-element array each —
+// 528 B of scratch): the 16 x 16 array of images lives in LDS, thread t < 128 runs butterfly t & 7 of column t >> 3 at every one of
+// the 7 stages.
+struct Blk16BuildArgs { const Te256 *np0, *dinv, *p0, *p1, *inner; uint8_t* A; unsigned long long* K; };
+__global__ __launch_bounds__(256) void k_blk16_build(Blk16BuildArgs a0, Blk16BuildArgs a1, size_t e) {
     using F = Secp256k1; using E = Fe256;
     __shared__ E Tm[256];
     __shared__ E csum[256];
+    const Blk16BuildArgs& a = blockIdx.x ? a1 : a0;
     const uint32_t tid = threadIdx.x;
-    if (tid < 16) {
-        E x[16];
-        for (int k = 0; k < 16; ++k) x[k] = (k == (int)tid) ? F::one() : F::zero();
-        for (int lh = 3; lh >= 1; --lh) {
-            const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
-            for (uint32_t g = 0; g < 8; ++g) {
+    // Tm[o * 16 + c] = component o of the image of unit vector c (column c of T)
+    Tm[tid] = ((tid >> 4) == (tid & 15u)) ? F::one() : F::zero();
+    __syncthreads();
+    const uint32_t c = tid >> 3, g = tid & 7u;
+    for (int st = 0; st < 7; ++st) {
+        if (tid < 128) {
+            if (st < 3) {                                   // decompose, pair distance 8, 4, 2
+                const int lh = 3 - st; const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
                 const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
-                const E a = x[idx], b = x[idx + h];
-                const E q1 = F::tmul(dinv[off + i], F::sub(b, a));
-                x[idx] = F::tmul_add(np0[off + i], q1, a); x[idx + h] = q1;
+                const E x = Tm[idx * 16 + c], y = Tm[(idx + h) * 16 + c];
+                const E q1 = F::tmul(a.dinv[off + i], F::sub(y, x));
+                Tm[idx * 16 + c] = F::tmul_add(a.np0[off + i], q1, x); Tm[(idx + h) * 16 + c] = q1;
+            } else if (st == 3) {                           // merged innermost pair
+                const E x = Tm[(2 * g) * 16 + c], d = F::sub(Tm[(2 * g + 1) * 16 + c], x);
+                Tm[(2 * g) * 16 + c] = F::tmul_add(a.inner[0], d, x); Tm[(2 * g + 1) * 16 + c] = F::tmul_add(a.inner[1], d, x);
+            } else {                                        // recombine, pair distance 2, 4, 8
+                const int lh = st - 3; const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
+                const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
+                const E x = Tm[idx * 16 + c], y = Tm[(idx + h) * 16 + c];
+                Tm[idx * 16 + c] = F::tmul_add(a.p0[off + i], y, x); Tm[(idx + h) * 16 + c] = F::tmul_add(a.p1[off + i], y, x);
             }
         }
-        {
-            const Te256 c0 = inner[0], c1 = inner[1];
-            for (uint32_t g = 0; g < 8; ++g) { const E a = x[2 * g], d = F::sub(x[2 * g + 1], a); x[2 * g] = F::tmul_add(c0, d, a); x[2 * g + 1] = F::tmul_add(c1, d, a); }
-        }
-        for (int lh = 1; lh <= 3; ++lh) {
-            const uint32_t h = 1u << lh; const size_t off = e - 2 * (size_t)h;
-            for (uint32_t g = 0; g < 8; ++g) {
-                const uint32_t i = g & (h - 1), idx = ((g >> lh) << (lh + 1)) + i;
-                const E a = x[idx], b = x[idx + h];
-                x[idx] = F::tmul_add(p0[off + i], b, a); x[idx + h] = F::tmul_add(p1[off + i], b, a);
-            }
-        }
-        for (int o = 0; o < 16; ++o) Tm[o * 16 + tid] = x[o];      // column tid of T
+        __syncthreads();
     }
-    blk16_expand(Tm, csum, Amat, Kc, tid);
+    blk16_expand(Tm, csum, a.A, a.K, tid);
 }
 
 // the 256 constants of a 16 x 16 map (shared memory, row-major [output][input], plain residues) -> int8 matrices + accumulator seeds
