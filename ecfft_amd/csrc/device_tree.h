@@ -566,17 +566,22 @@ public:
         auto local_part = [&]() -> bool {
             try {
                 size_t total = 64 + 3 * L_ + 4096;
-                for (unsigned l = 0; l <= lc; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
-                total += log_p * (shard_set_elems(hc) + 5 * c + 256);
+                // round 4: the chain goes up to T_2c — the lowest top level (groups of two ranks) runs REDUNDANTLY on both ranks of a
+                // pair from one exchange instead of as four split EXTENDs with nine (api_exit_split), so that level needs the whole
+                // tree and no share
+                for (unsigned l = 0; l <= lc + 1; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
+                if (P > 2) total += log_p * (shard_set_elems(hc) + 5 * c + 256);      // P = 2: the pair level is the only top level — no share at all
                 total += low16_elems();
                 ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
                 arena_cap_ = total; arena_used_ = 0;
                 if (!upload_points(fdev, s)) return false;
                 f_ = fdev;                                               // build_tree reads f_
-                if (!ensure_scratch(c)) return false;
+                if (!ensure_scratch(2 * c)) return false;
                 create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
                 trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
-                for (unsigned l = 0; l <= lc; ++l) if (!build_tree(l, s)) return false;
+                for (unsigned l = 0; l <= lc + 1; ++l) if (!build_tree(l, s)) return false;
+                pair_full_ = trees_[lc + 1]; have_pair_full_ = true;     // the level-Q=2 iteration below re-points trees_[lc + 1] at the rank's shares (the distributed
+                                                                         // build of the level above still splits T_2c over the pairs); the full tables stay in the arena
                 if (!build_low16(lc, s)) return false;
                 lc_inv = take(L_);
                 std::vector<E> h(L_, F::one());
@@ -594,6 +599,7 @@ public:
         bool ok = true;
         E *pz0[2] = {nullptr, nullptr}, *pz1[2] = {nullptr, nullptr};     // the level below: z0z0 / z1z1 _rem_xnn_s on the rank's S0 / S1 positions
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
+            if (P == 2) break;                                             // the shares of T_2c only feed the distributed build of the level above
             const size_t half = Q / 2, m = c * Q, stride = N_ / m;
             const unsigned lm = ilog2(m), lq = ilog2(Q), lh = ilog2(half);
             const int base = (int)((rank / Q) * Q), a = (int)rank - base, g = a / (int)half, ap = a % (int)half, subbase = base + g * (int)half;
@@ -1190,10 +1196,18 @@ public:
         const size_t P = (size_t)tr.world, c = n / P, hc = c / 2;
         if ((P & (P - 1)) || c < 2 * P || hc < P) return false;
         E *cur = nullptr, *e0 = nullptr, *e1 = nullptr, *t0 = nullptr, *h0 = nullptr, *h1 = nullptr, *A = nullptr, *B = nullptr, *x0 = nullptr, *x1 = nullptr, *Rb = nullptr;
-        if (!collective_prepare(tr, 3, n, 0, s, [&] { cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
-                                                      x0 = temp(hc); x1 = temp(hc); Rb = temp(c); })) return false;
-        bool ok = true;
+        E *blk = nullptr, *Y = nullptr;
         const bool sh = shard_mode();
+        // round 4: the level of the PAIRS (Q = 2, blocks of 2c) runs redundantly on both ranks of a pair: ONE exchange hands each rank
+        // its partner's (e0, e1) share, the level itself is the single-GPU EXIT level of the 2c block on the full tree T_2c (fused
+        // passes, no pack / unpack, no cyclic passes), and each rank keeps its own half of [u0 | v0] — which IS its chunk for the
+        // local levels: 1 exchange instead of 9 (8 of the split EXTENDs + the re-blocking one) for twice the level's arithmetic.
+        // EXIT-shard contexts carry T_2c for it (build_exit_shard); ECFFT_SPLIT_Q2_SPLIT=1 keeps the split form on a FULL context (A/B).
+        const bool q2_local = sh || !q2_split_;
+        if (!collective_prepare(tr, 3, n, q2_local ? 1 : 0, s, [&] { cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
+                                                      x0 = temp(hc); x1 = temp(hc); Rb = temp(c);
+                                                      if (q2_local) { blk = temp(2 * c); Y = temp(2 * c); if (!ensure_scratch(2 * c)) throw DeviceAllocError(); } })) return false;
+        bool ok = true;
         {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
             const size_t cpp = hc / P; const unsigned lp = ilog2(P);
             E* S = cur;                                                      // [target r'][e0 piece | e1 piece]
@@ -1208,6 +1222,27 @@ public:
             const size_t half = Q / 2, m = c * Q;
             const int base = (int)((tr.rank / Q) * Q), a = tr.rank - base, ap = a % (int)half;
             const Tree& T = trees_[ilog2(m)];
+            if (Q == 2 && q2_local) {
+                // (e0, e1)[j] = evaluations 2i, 2i + 1 of the 2c block for i = 2j + a; the partner holds i = 2j + (1 - a)
+                E *pe0 = h0, *pe1 = h1;
+                P2P snd[2] = {{base + 1 - a, e0, hc * sizeof(E)}, {base + 1 - a, e1, hc * sizeof(E)}};
+                P2P rcv[2] = {{base + 1 - a, pe0, hc * sizeof(E)}, {base + 1 - a, pe1, hc * sizeof(E)}};
+                ok = tr.exchange(snd, 2, rcv, 2, s);
+                if (!ok) break;
+                { const size_t aa = (size_t)a, bb = (size_t)(1 - a);
+                  foreach_n(s, hc, [=] __device__(size_t j) {
+                      blk[2 * (2 * j + aa)] = e0[j]; blk[2 * (2 * j + aa) + 1] = e1[j];
+                      blk[2 * (2 * j + bb)] = pe0[j]; blk[2 * (2 * j + bb) + 1] = pe1[j];
+                  }); }
+                const unsigned lm = ilog2(m);
+                if (sh) { if (!have_pair_full_) { ok = false; break; } ovr_tree_ = &pair_full_; ovr_set_ = nullptr; }     // the full T_2c an EXIT-shard context keeps aside
+                exit_levels(blk, Y, m, 1, s, scratch_, lm, lm);            // src/fftree.rs:200-224 for the block: Y = [u0 | v0]
+                ovr_tree_ = nullptr;
+                ok = exit(Y + (size_t)a * c, out, c, 1, s);                   // this rank's half is its chunk of the local levels
+                ok = ok && hipGetLastError() == hipSuccess;
+                temps_done();
+                return ok;
+            }
             // the rank's entries of 1/xnn_s on S0, xnn_s on S1, 1/z0_s1 and z0z0_rem_xnn_s on S0 / S1 (positions j*Q + a of each
             // half): strided views of the full tables, or the compact arrays an EXIT-shard context holds in the same fields
             const size_t s2 = sh ? 1 : 2 * Q, s1 = sh ? 1 : Q;
@@ -1356,7 +1391,7 @@ public:
         const unsigned ll = log_low_for(n);
         unsigned l_stop = (l_to == 1 && l_from >= ll) ? ll : l_to - 1;      // levels l_stop..1 run fused in k_exit_low
         for (unsigned l = l_from; l > l_stop; --l) {
-            const Tree& T = trees_[l];
+            const Tree& T = tree_at(l);
             E* dst = (l == l_to && out != in) ? out : (cur == bufA ? bufB : bufA);
             // The reference's pointwise steps of this level (8.5 n + 8.5 e algorithmic element moves)
             // are all folded into the first load / last store of the four EXTEND cores:
@@ -1993,6 +2028,8 @@ private:
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
+    Tree pair_full_{}; bool have_pair_full_ = false;                    // EXIT-shard contexts: the full tree T_2c (c = n / world) of the redundant pair level
+    bool q2_split_ = getenv("ECFFT_SPLIT_Q2_SPLIT") != nullptr;        // A/B switch (full contexts): the pair level of a split EXIT as four split EXTENDs
     bool col256_off_ = getenv("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
     bool row256_off_ = getenv("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)
     bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule

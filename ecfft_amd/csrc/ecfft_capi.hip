@@ -967,6 +967,17 @@ int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn 
     *out = c;
     return ECFFT_OK;
 }
+int ecfft_comm_init_projection(int world, int rank, int device, double delay_us, double link_gbps, ecfft_comm** out) {
+    if (!out) return ECFFT_ERR_BAD_ARG;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || delay_us < 0 || link_gbps < 0) return ECFFT_ERR_BAD_ARG;
+    ecfft_comm* c = new (std::nothrow) ecfft_comm();
+    if (!c) return ECFFT_ERR_HIP;
+    c->t = new (std::nothrow) ProjectionTransport(world, rank, device, delay_us, link_gbps);
+    if (!c->t) { delete c; return ECFFT_ERR_HIP; }
+    *out = c;
+    return ECFFT_OK;
+}
 void ecfft_comm_destroy(ecfft_comm* comm) {
     if (!comm) return;
     DeviceGuard dev(comm->t ? comm->t->device : 0);

@@ -176,6 +176,41 @@ private:
     ecfft_exchange_fn fn_; void* user_;
 };
 
+// ---- projection transport (measurement only) -------------------------------------------------------------------------------
+// ONE rank of a `world`-rank job timed on its own: an exchange costs what the model says — `delay_us` of latency plus the largest
+// per-peer message at `gbps` GB/s — as a kernel that spins on the constant 100 MHz wall clock ON THE CALLER'S STREAM, and moves
+// the rank's own send buffers into its receive buffers (device-to-device), so that every kernel downstream runs on initialised
+// memory of the right size.  The RESULTS ARE MEANINGLESS (no data of another rank ever arrives); the TIMELINE of the stream is
+// that of a rank whose peers answer after exactly the modelled time: per-rank compute, launches, exchanges, bytes and the exposed
+// communication time of the split transforms without the hardware (tools/split_project.py).  The transforms are data oblivious,
+// so the wrong data changes no launch.
+__global__ void k_spin_us(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+class ProjectionTransport : public Transport {
+public:
+    ProjectionTransport(int world_, int rank_, int device_, double delay_us, double gbps) : delay_us_(delay_us), gbps_(gbps) { world = world_; rank = rank_; device = device_; }
+protected:
+    bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
+        size_t worst = 0;                                                      // one message per link: the largest one sets the time
+        for (int i = 0; i < ns; ++i) if (sends[i].peer != rank && sends[i].bytes > worst) worst = sends[i].bytes;
+        double us = delay_us_ + (gbps_ > 0 ? (double)worst / (gbps_ * 1e3) : 0.0);
+        bool remote = false;
+        for (int i = 0; i < ns; ++i) remote = remote || sends[i].peer != rank;
+        if (!remote) us = 0.0;                                                 // self send / receive only: no link involved
+        if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, s, (unsigned long long)(us * 100.0));
+        for (int i = 0; i < nr; ++i) {                                         // i-th receive <- i-th send (sizes agree for the group exchanges of the split transforms)
+            const P2P& src = sends[i < ns ? i : ns - 1];
+            const size_t b = recvs[i].bytes < src.bytes ? recvs[i].bytes : src.bytes;
+            if (b && recvs[i].ptr != src.ptr && hipMemcpyAsync(recvs[i].ptr, src.ptr, b, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+        }
+        return true;
+    }
+private:
+    double delay_us_, gbps_;
+};
+
 }  // namespace ecfft
 
 struct ecfft_comm {

@@ -140,6 +140,18 @@ class Comm:
         fftree._check(L.ecfft_comm_init_callback(world, rank, device, cb, None, ctypes.byref(h)))
         return Comm(h, keep=cb)
 
+    @staticmethod
+    def projection(world, rank, device=0, delay_us=25.0, link_gbps=0.0):
+        """MEASUREMENT ONLY (ecfft_comm_init_projection): one rank of a `world`-rank job timed on its own — exchanges cost the
+        modelled time on the stream, results are meaningless"""
+        from . import fftree
+        L = fftree.lib()
+        L.ecfft_comm_init_projection.restype = ctypes.c_int
+        L.ecfft_comm_init_projection.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]
+        h = ctypes.c_void_p()
+        fftree._check(L.ecfft_comm_init_projection(world, rank, device, float(delay_us), float(link_gbps), ctypes.byref(h)))
+        return Comm(h)
+
     def abort(self):
         """ncclCommAbort (RCCL transports): unblocks exchanges in flight; later sharded calls on this communicator fail.  Returns
         False for a callback transport.  May be called from another thread than the blocked one."""

@@ -138,7 +138,9 @@ int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, un
  * Arguments: device pointers only; `in` / `out` = this rank's BLOCK shard (len / world elements, may alias); world = 2^k;
  * len / world >= 2 * world.  Every rank of the communicator makes the same call with the same len.  Asynchronous on `stream`.
  * Exchanges (grouped send / receive calls) per transform: EXTEND 4 (2 per cyclic side saved, ecfft_extend_sharded_layout); ENTER
- * 3 per top level + 1 (Q = 2: 1); EXIT 1 + 9 per top level — inside a level every vector stays cyclic over its group. */
+ * 3 per top level + 1 (Q = 2: 1); EXIT 1 + 9 per top level above the pairs + 1 — inside a level every vector stays cyclic over its
+ * group; the level of the PAIRS of ranks (blocks of 2 len / world) runs redundantly on both ranks of a pair from one exchange
+ * (round 4), so EXIT takes 2 / 11 / 20 exchanges at world = 2 / 4 / 8 (before: 10 / 19 / 28). */
 typedef struct ecfft_comm ecfft_comm;
 #define ECFFT_COMM_ID_BYTES 128
 /* n sends and n receives of device buffers that must progress together; return 0 on success */
@@ -147,6 +149,12 @@ typedef int (*ecfft_exchange_fn)(void* user, int n_send, const int* send_peer, c
 int ecfft_comm_get_unique_id(void* id_out);                                                      /* ECFFT_COMM_ID_BYTES bytes */
 int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out);
 int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn fn, void* user, ecfft_comm** out);
+/* MEASUREMENT ONLY: one rank of a `world`-rank job timed on its own.  Every exchange with a remote peer costs delay_us + (largest
+ * message of the exchange) / link_gbps GB/s as a spinning kernel on the caller's stream, and the rank's own send buffers are copied
+ * into its receive buffers: the stream's timeline is that of a rank whose peers answer after exactly the modelled time; the
+ * RESULTS of a sharded call on such a communicator are meaningless (tools/split_project.py: per-rank compute, exchanges, bytes and
+ * exposed communication time of the split transforms without multi-GPU hardware).  link_gbps = 0: latency only. */
+int ecfft_comm_init_projection(int world, int rank, int device, double delay_us, double link_gbps, ecfft_comm** out);
 void ecfft_comm_destroy(ecfft_comm* comm);
 /* RCCL transports: ncclCommAbort — unblocks the exchanges in flight (a peer died or never arrived) and makes every later sharded
  * call on this communicator return ECFFT_ERR_HIP; may be called from another host thread than the blocked one.  ECFFT_ERR_HIP for a

@@ -424,8 +424,57 @@ def test_exit_shard_context_on_one_gpu(field, n, P):
     torch.cuda.synchronize()
     for r in range(P):
         assert torch.equal(got[r], want[r * c:(r + 1) * c]), (field, n, P, r)
-        if n >= 1 << 16:
+        if n >= 1 << 16 and P > 2:       # P = 2: the pair level runs on the full tree T_n (round 4), the context is the whole chain
             assert got[("bytes", r)] < full_bytes
+        if P == 2 and n >= 1 << 16:
+            assert got[("bytes", r)] <= 1.15 * full_bytes       # the whole chain + the pinned temporaries of the sharded call
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 13, 2), ("secp256k1", 1 << 14, 4), ("m31", 1 << 18, 8)])
+def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, P, monkeypatch):
+    """round 4: the lowest top level of a split EXIT — groups of two ranks, blocks of 2n/P — is one exchange
+    (each rank gets its partner's share) and the single-GPU EXIT level of the block on BOTH ranks, instead of four split EXTENDs
+    with eight exchanges plus the re-blocking one.  Exchanges per EXIT: 1 + 9 (log2 P - 1) + 1 instead of 1 + 9 log2 P — checked on
+    a full context against its own split form (ECFFT_SPLIT_Q2_SPLIT=1) and on EXIT-shard contexts (which now carry T_2n/P for it),
+    bit for bit against the single-GPU EXIT of arbitrary evaluations."""
+    import torch
+    import ecfft_amd
+    F = ecfft_amd.FIELDS[field]
+    c = n // P
+    full_tree = F.build_fftree(n)
+    rng = np.random.default_rng(8)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = full_tree.exit(x)
+    torch.cuda.synchronize()
+    logp = P.bit_length() - 1
+    counts = {}
+    for mode in ("full", "full-split-pairs", "shard"):
+        if mode == "full-split-pairs":
+            monkeypatch.setenv("ECFFT_SPLIT_Q2_SPLIT", "1")
+        got, nx = {}, {}
+
+        def body(rank, make_comm):
+            comm = make_comm()
+            ctx = F.build_exit_shard(n, comm) if mode == "shard" else F.build_fftree(n)
+            mine = x[rank * c:(rank + 1) * c].clone()
+            comm.stats(True)
+            got[rank] = ctx.exit_sharded(comm, mine, n)
+            nx[rank] = comm.stats()["exchanges"]
+
+        _thread_ranks(P, body)
+        if mode == "full-split-pairs":
+            monkeypatch.delenv("ECFFT_SPLIT_Q2_SPLIT")
+        for rank in range(P):
+            assert torch.equal(got[rank], want[rank * c:(rank + 1) * c]), (mode, rank)
+        counts[mode] = nx[0]
+    assert counts["full-split-pairs"] == 1 + 9 * logp
+    assert counts["full"] == counts["shard"] == 1 + 9 * (logp - 1) + 1
+    assert counts["full"] <= 0.8 * counts["full-split-pairs"] or logp > 2          # >= 20 % fewer exchange latencies (P = 2: 10 -> 2, P = 4: 19 -> 11, P = 8: 28 -> 20)
 
 
 @pytest.mark.gpu
