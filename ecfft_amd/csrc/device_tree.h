@@ -113,6 +113,11 @@ public:
     // tree is installed (the sharded EXIT build needs two different shares of one tree)
     const Tree& tree_at(unsigned log_m) const { return (ovr_tree_ && ovr_tree_->log_m == log_m) ? *ovr_tree_ : trees_[log_m]; }
     const HostTree<F>& host() const { return host_; }
+    int low_map(int dir) const {
+        if (trees_.size() > 5 && trees_[5].low32_A[dir]) return 32;
+        if (trees_.size() > 4 && trees_[4].low16_A[dir]) return 16;
+        return 0;
+    }
     const E* f_device() const { return f_; }
     std::mutex& lock() { return mu_; }
     // test hook, process wide: the rank whose local part of the next collective ecfft_build_exit_shard reports failure (-1: none).
@@ -1803,7 +1808,7 @@ private:
     // The four lowest levels of ENTER and of EXIT as ONE 16 x 16 map each for the matrix cores (LevelTables::low16_A, read by the
     // 1024-element low-level kernels): every 16-block of a transform goes through the same levels on the same tables, so the maps
     // are the images of the 16 unit vectors under this context's own level code (16 transforms of 16 points in one batched call).
-    static size_t low16_elems() { return sizeof(E) == 32 ? 2 * (Blk16::kArenaElems + 8) : 0; }
+    static size_t low16_elems() { return sizeof(E) == 32 ? 2 * (Blk16::kArenaElems + 8) + 2 * (Blk16::kArenaElems32 + 8) : 0; }   // + the two low32 maps
     bool build_low16(unsigned l_top, hipStream_t s) {
         if constexpr (sizeof(E) == 32) {
             if (l_top < kLogLowSmall || mfma_off_ || low16_off_) return true;
@@ -1816,6 +1821,22 @@ private:
                 unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes);
                 hipLaunchKernelGGL(k_blk16_from_matrix, dim3(1), dim3(256), 0, s, O, A, K, true);
                 T.low16_A[dir] = A; T.low16_K[dir] = K;
+            }
+            // round 4: the FIVE lowest levels as one 32 x 32 map per 32-block, for the 1024-element low-level kernels (low32_mask_:
+            // bit 0 ENTER, bit 1 EXIT) — the images of the 32 unit vectors under the level code (32 transforms of 32 points)
+            if (l_top >= kLogLow && low32_mask_) {
+                Tree& T5 = trees_[5];
+                E* I32 = temp(1024); E* O32 = temp(1024); E* CS = temp(1024);
+                foreach_n(s, 1024, [=] __device__(size_t j) { I32[j] = ((j >> 5) == (j & 31)) ? F::one() : F::zero(); });
+                for (int dir = 0; dir < 2; ++dir) {
+                    if (!((low32_mask_ >> dir) & 1u)) continue;
+                    if (dir == 0) enter_levels(I32, O32, 32, 32, s, scratch_, 1, 5); else exit_levels(I32, O32, 32, 32, s, scratch_, 5, 1);
+                    uint8_t* A = reinterpret_cast<uint8_t*>(take(Blk16::kArenaElems32));
+                    unsigned long long* K = reinterpret_cast<unsigned long long*>(A + Blk16::kABytes32);
+                    hipLaunchKernelGGL(k_blk32_expand, dim3(4), dim3(256), 0, s, (const E*)O32, A, CS, true);
+                    hipLaunchKernelGGL(k_blk32_seeds, dim3(1), dim3(32), 0, s, (const E*)CS, K);
+                    T5.low32_A[dir] = A; T5.low32_K[dir] = K;
+                }
             }
         }
         return hipGetLastError() == hipSuccess;
@@ -2025,6 +2046,10 @@ private:
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     mutable std::map<uint64_t, TE*> full_cyc_; mutable size_t full_cyc_bytes_ = 0;   // compact cyclic tables of a FULL context (full_cyclic_table)
     bool full_cyc_off_ = getenv("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
+    // bit 0: ENTER levels 1..5, bit 1: EXIT levels 5..1 as one 32-point map (low32).  OFF by default: measured on MI355X (profiles/r04/low32_ab.txt)
+    // the 32-point phase costs what it removes — level 5 is four 16-point phases + five pointwise steps (~35 us per tile), the phase
+    // streams 1 MiB of matrices per tile and runs twice the MFMAs of low16 (k_exit_low 1.63 -> 1.65-1.69 ms, k_enter_low 0.66 -> 0.66)
+    unsigned low32_mask_ = getenv("ECFFT_LOW32") ? (unsigned)atoi(getenv("ECFFT_LOW32")) : 0u;
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)

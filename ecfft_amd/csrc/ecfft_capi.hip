@@ -1174,6 +1174,32 @@ int ecfft_selftest_blk16_small(const void* matrix256, const void* x, void* out, 
     return ok ? ECFFT_OK : ECFFT_ERR_HIP;
 }
 
+int ecfft_selftest_blk32(const void* matrix1024, const void* x, void* out, size_t n, int device) {
+    if (!matrix1024 || !x || !out || !n || n % 1024) return ECFFT_ERR_BAD_ARG;
+    if (!have_device(device)) return ECFFT_ERR_HIP;
+    DeviceGuard dev(device);
+    if (!dev.ok) return ECFFT_ERR_HIP;
+    Fe256 *dT = nullptr, *dx = nullptr, *dcs = nullptr; uint8_t* dA = nullptr;
+    bool ok = hipMalloc(&dT, 1024 * sizeof(Fe256)) == hipSuccess && hipMalloc(&dcs, 1024 * sizeof(Fe256)) == hipSuccess && hipMalloc(&dx, n * sizeof(Fe256)) == hipSuccess &&
+              hipMalloc(&dA, Blk16::kABytes32 + Blk16::kKWords32 * 8) == hipSuccess;
+    ok = ok && hipMemcpy(dT, matrix1024, 1024 * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dx, x, n * sizeof(Fe256), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        unsigned long long* dK = reinterpret_cast<unsigned long long*>(dA + Blk16::kABytes32);
+        hipLaunchKernelGGL(k_blk32_expand, dim3(4), dim3(256), 0, nullptr, (const Fe256*)dT, dA, dcs, false);
+        hipLaunchKernelGGL(k_blk32_seeds, dim3(1), dim3(32), 0, nullptr, (const Fe256*)dcs, dK);
+        hipLaunchKernelGGL(k_blk32_apply, dim3((unsigned)(n / 1024)), dim3(512), 0, nullptr, dx, dA, dK);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dx, n * sizeof(Fe256), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(dT); (void)hipFree(dx); (void)hipFree(dA); (void)hipFree(dcs);
+    return ok ? ECFFT_OK : ECFFT_ERR_HIP;
+}
+// which composite map the 1024-element low-level kernels of this context run for the lowest levels of ENTER (dir 0) / EXIT (dir 1):
+// 32 (levels 1..5), 16 (levels 1..4) or 0 (level code)
+int ecfft_ctx_low_map(const ecfft_ctx* ctx, int dir) {
+    if (!ctx || dir < 0 || dir > 1 || ctx->field != ECFFT_FIELD_SECP256K1 || !ctx->secp) return 0;
+    return ctx->secp->low_map(dir);
+}
+
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);

@@ -1188,6 +1188,9 @@ struct LevelTables {
     // low16_A / _K (only in the entry of the tree with 16 leaves): levels 1..4 of ENTER [0] and levels 4..1 of EXIT [1] of a 16-block
     // as ONE 16 x 16 map in the same form - every 16-block of a transform goes through the same four levels on the same tables
     const uint8_t* low16_A[2]; const unsigned long long* low16_K[2];
+    // low32_A / _K (only in the entry of the tree with 32 leaves; round 4): levels 1..5 of ENTER [0] / 5..1 of EXIT [1] of a 32-block as
+    // ONE 32 x 32 map (1 MiB of matrices each, Blk16::phase32); nullptr: low16 (or the level code) runs
+    const uint8_t* low32_A[2]; const unsigned long long* low32_K[2];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1519,9 +1522,16 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 2)) void k_ent
     __syncthreads();
     uint32_t l_first = 1;
     if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) {
-        // levels 1..4 on the matrix cores: one 16 x 16 map per 16-block (LevelTables::low16_A)
+        // levels 1..5 on the matrix cores as one 32 x 32 map per 32-block (LevelTables::low32_A), else
+        // levels 1..4 as one 16 x 16 map per 16-block (LevelTables::low16_A)
         const uint8_t* lA = trees[4].low16_A[0];
-        if (lA) {
+        const uint8_t* lA32 = trees[5].low32_A[0];
+        if (lA32) {
+            Blk16::to_operand_form32(cur, tid);
+            Blk16::phase32(cur, lA32, trees[5].low32_K[0], tid);
+            Blk16::from_swizzled32(cur, tid);
+            l_first = 6;
+        } else if (lA) {
             Blk16::APre pre = Blk16::prefetch(lA, tid);
             __builtin_amdgcn_sched_barrier(0);
             Blk16::to_operand_form<BLK>(cur, T, tid);
@@ -1670,7 +1680,9 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
     __syncthreads();
     uint32_t l_last = 1;
     const uint8_t* lA = nullptr;
+    const uint8_t* lA32 = nullptr;
     if constexpr (sizeof(E) == 32 && ((LOG_TILE == 10 && BLK == 512) || (LOG_TILE == 8 && BLK == 128))) { lA = trees[4].low16_A[1]; if (lA) l_last = 5; }
+    if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) { lA32 = trees[5].low32_A[1]; if (lA32) l_last = 6; }
     for (uint32_t l = log_tile; l >= l_last; --l) {
         const LevelTables<F>& L = trees[l];
         const uint32_t le = l - 1, e = 1u << le;
@@ -1789,6 +1801,11 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
         __syncthreads();
     }
     if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) {
+        if (lA32) {             // levels 5..1 on the matrix cores: one 32 x 32 map per 32-block
+            Blk16::to_operand_form32(cur, tid);
+            Blk16::phase32(cur, lA32, trees[5].low32_K[1], tid);
+            Blk16::from_swizzled32(cur, tid);
+        } else
         if (lA) {               // levels 4..1 on the matrix cores: one 16 x 16 map per 16-block
             Blk16::APre pre = Blk16::prefetch(lA, tid);
             __builtin_amdgcn_sched_barrier(0);

@@ -415,6 +415,99 @@ struct Blk16 {
         return load_swizzled(sub, tid);
     }
 
+    // ---------------------------------------------------------------------------------------------------------------------
+    // A 32-POINT map on a 1024-element array = 32 blocks of 32 (round 4: the FIVE lowest levels of ENTER / EXIT as one map, "low32").
+    // 1024 constants = 1 MiB of matrices per direction, streamed once per tile (L2-resident: every tile of the launch reads the same
+    // ones); 32 blocks = the 32 columns of ONE v_mfma_i32_32x32x32_i8, so a tile is 32 outputs x 32 inputs = 1024 MFMAs (the 16-point
+    // map: 512) and 1024 normalisations.  It costs about 3 us more per tile than the 16-point map and removes a whole level — 33
+    // sweep-steps of k_exit_low, 9 of k_enter_low.  (A 64-point map would stream 4 MiB per tile through a 4 MiB L2: not built.)
+    // Element j = 32 n + i of block n; chunk q = 2j + half sits at (q & ~15) | ((q ^ n) & 15): the operand reads of a wave take the same
+    // (i, half) of the 32 blocks (1 KiB apart), and each of ds_read_b128's lane groups holds 16 different n mod 16.
+    static constexpr int NB32 = 32;
+    static constexpr size_t kABytes32 = (size_t)NB32 * NB32 * 1024;
+    static constexpr size_t kKWords32 = (size_t)NB32 * 8;
+    static constexpr size_t kArenaElems32 = (kABytes32 + kKWords32 * 8) / sizeof(E);
+    __host__ __device__ static inline uint32_t phys32(uint32_t j, uint32_t hh) {
+        const uint32_t q = 2 * j + hh;
+        return (q & ~15u) | ((q ^ (j >> 5)) & 15u);
+    }
+    // plain 1024-element tile -> operand form of the 32-point map (bytes xor 0x80).  512 threads.  Ends with a barrier.
+    __device__ static __forceinline__ void to_operand_form32(E* tile, uint32_t tid) {
+        uint4* lds = reinterpret_cast<uint4*>(tile);
+        const uint32_t j0 = tid, j1 = 512 + tid;
+        const uint4 a0 = lds[2 * j0], a1 = lds[2 * j0 + 1], b0 = lds[2 * j1], b1 = lds[2 * j1 + 1];
+        __syncthreads();
+        const uint32_t X = 0x80808080u;
+        lds[phys32(j0, 0)] = make_uint4(a0.x ^ X, a0.y ^ X, a0.z ^ X, a0.w ^ X);
+        lds[phys32(j0, 1)] = make_uint4(a1.x ^ X, a1.y ^ X, a1.z ^ X, a1.w ^ X);
+        lds[phys32(j1, 0)] = make_uint4(b0.x ^ X, b0.y ^ X, b0.z ^ X, b0.w ^ X);
+        lds[phys32(j1, 1)] = make_uint4(b1.x ^ X, b1.y ^ X, b1.z ^ X, b1.w ^ X);
+        __syncthreads();
+    }
+    __device__ static __forceinline__ void from_swizzled32(E* tile, uint32_t tid) {
+        const uint4* lds = reinterpret_cast<const uint4*>(tile);
+        E x[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t j = tid + 512u * k;
+            const uint4 a = lds[phys32(j, 0)], b = lds[phys32(j, 1)];
+            x[k].l[0] = a.x; x[k].l[1] = a.y; x[k].l[2] = a.z; x[k].l[3] = a.w; x[k].l[4] = b.x; x[k].l[5] = b.y; x[k].l[6] = b.z; x[k].l[7] = b.w;
+        }
+        __syncthreads();
+        tile[tid] = x[0]; tile[tid + 512] = x[1];
+        __syncthreads();
+    }
+    // `sub`: 1024 elements in operand form (phys32).  512 threads: wave w produces outputs 4w .. 4w + 3 of the 32 blocks (four 32 x 32
+    // accumulators); the register swap pairs outputs (4w, 4w + 1) and (4w + 2, 4w + 3): lane (h, n) ends with outputs 4w + h and
+    // 4w + 2 + h of block n.  Results (plain bytes) at the swizzled positions; ends with a barrier.
+    __device__ static __forceinline__ void phase32(E* sub, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc, uint32_t tid) {
+        uint4* lds = reinterpret_cast<uint4*>(sub);
+        const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 31, h = L >> 5;
+        const gchar ap = (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(4 * w) * NB32) * 1024 + L * 16;
+        auto ldA32 = [&](int oo, int i) { return *(gv4)(ap + ((size_t)oo * NB32 + (size_t)i) * 1024); };
+        const char* lb = reinterpret_cast<const char*>(lds);
+        auto ldB = [&](int i) { const uint32_t c = 64u * n + 2u * (uint32_t)i + h; const uint4 b = *reinterpret_cast<const uint4*>(lb + 16u * ((c & ~15u) | ((c ^ n) & 15u))); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
+        // two passes of two outputs each (two 32 x 32 accumulators): four at once need > 128 VGPRs next to the low-level kernels' other
+        // registers and spill; the data operands are read from LDS again in the second pass
+        E outz[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {                                // unrolled: outz[pr] must be a register, not an indexed array
+            v16i acc0 = {0}, acc1 = {0};
+            gchar pa = ap + (size_t)(2 * pr) * NB32 * 1024;            // matrices (4w + 2 pr, i) at pa + 1024 i, (4w + 2 pr + 1, i) 32 KiB above
+            v4i A0 = *(gv4)pa, A1 = *(gv4)(pa + 32 * 1024), nA0 = *(gv4)(pa + 1024), nA1 = *(gv4)(pa + 33 * 1024);     // two inputs in flight
+            pa += 2048;
+            uint32_t cb = 64u * n + h;                                   // chunk index of (block n, input i, half h) = 64 n + 2 i + h
+            auto ldBc = [&](uint32_t c) { const uint4 b = *reinterpret_cast<const uint4*>(lb + 16u * ((c & ~15u) | ((c ^ n) & 15u))); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
+            v4i B0 = ldBc(cb);
+#pragma unroll 2
+            for (int i = 0; i < NB32; ++i) {
+                v4i n2A0 = nA0, n2A1 = nA1, nB = B0;
+                if (i + 2 < NB32) { n2A0 = *(gv4)pa; n2A1 = *(gv4)(pa + 32 * 1024); pa += 1024; }
+                if (i + 1 < NB32) { cb += 2; nB = ldBc(cb); }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A0, B0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A1, B0, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                A0 = nA0; A1 = nA1; nA0 = n2A0; nA1 = n2A1; B0 = nB;
+            }
+            int lo[16], hi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                auto p = __builtin_amdgcn_permlane32_swap((unsigned)acc0[r], (unsigned)acc1[r], false, false);
+                lo[r] = (int)p[0]; hi[r] = (int)p[1];
+            }
+            outz[pr] = normalise<true>(lo, hi, Kc + (4 * w + 2 * pr + h) * 8);
+        }
+        __syncthreads();        // every operand read of this phase is done
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t j = n * NB32 + 4 * w + 2 * pr + h;
+            lds[phys32(j, 0)] = make_uint4(outz[pr].l[0], outz[pr].l[1], outz[pr].l[2], outz[pr].l[3]);
+            lds[phys32(j, 1)] = make_uint4(outz[pr].l[4], outz[pr].l[5], outz[pr].l[6], outz[pr].l[7]);
+        }
+        __syncthreads();
+    }
+
     // ---- construction: the 16 x 16 matrix of the tree (the kernels' own stage code applied to the unit vectors), its
     // int8 expansion and the accumulator seeds.  One workgroup of 256 threads per (tree, parity).
     __device__ static inline void signed_digits(const E& c, int8_t d[32]) {
@@ -509,6 +602,47 @@ __global__ __launch_bounds__(256) void k_blk16_from_matrix(const Fe256* __restri
     Tm[threadIdx.x] = T[transposed ? (threadIdx.x & 15u) * 16u + (threadIdx.x >> 4) : threadIdx.x];
     blk16_expand(Tm, csum, Amat, Kc, threadIdx.x);
 }
+// The 32-point map given as 1024 plain constants T[o * 32 + i] (or transposed: images of the unit vectors = columns): int8 matrices
+// (one thread per constant, grid = 4 x 256) and the per-constant sums sum_j c 2^(8j); k_blk32_seeds turns those into the 32 x 8
+// accumulator seeds (as blk16_expand does for 16 x 16).
+__global__ __launch_bounds__(256) void k_blk32_expand(const Fe256* __restrict__ T, uint8_t* __restrict__ Amat, Fe256* __restrict__ csum, bool transposed) {
+    using F = Secp256k1; using E = Fe256;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x, o = idx >> 5, i = idx & 31u;
+    E c = T[transposed ? i * 32u + o : idx], sum = F::zero();
+    const E f256 = F::from_u32(256);
+    uint8_t* A = Amat + (size_t)idx * 1024;
+    for (uint32_t j = 0; j < 32; ++j) {
+        int8_t d[32];
+        Blk16::signed_digits(c, d);
+        const uint32_t hh = j >> 4, q = j & 15;
+        for (uint32_t b = 0; b < 32; ++b) A[(Blk16::row_of_digit(b) + 32 * hh) * 16 + q] = (uint8_t)d[b];
+        sum = F::add(sum, c);
+        c = F::mul(c, f256);
+    }
+    csum[idx] = sum;
+}
+__global__ __launch_bounds__(32) void k_blk32_seeds(const Fe256* __restrict__ csum, unsigned long long* __restrict__ Kc) {
+    using F = Secp256k1; using E = Fe256;
+    const uint32_t o = threadIdx.x;
+    E s = F::zero();
+    for (int i = 0; i < 32; ++i) s = F::add(s, csum[o * 32 + i]);
+    E off; off.l[0] = 977u << 18; off.l[1] = 1u << 19; for (int i = 2; i < 8; ++i) off.l[i] = 1u << 18;
+    const E kap = F::sub(F::mul(s, F::from_u32(128)), off);
+    for (int g = 0; g < 8; ++g) Kc[o * 8 + g] = (1ull << 50) + kap.l[g];
+}
+// test hook: the 32-point phase alone on tiles of 1024 elements (grid = tiles, 512 threads), in place
+__global__ __launch_bounds__(512) void k_blk32_apply(Fe256* __restrict__ data, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc) {
+    __shared__ Fe256 tile[1024];
+    const uint32_t tid = threadIdx.x;
+    Fe256* g = data + (size_t)blockIdx.x * 1024;
+    tile[tid] = g[tid]; tile[tid + 512] = g[tid + 512];
+    __syncthreads();
+    Blk16::to_operand_form32(tile, tid);
+    Blk16::phase32(tile, Amat, Kc, tid);
+    Blk16::from_swizzled32(tile, tid);
+    g[tid] = tile[tid]; g[tid + 512] = tile[tid + 512];
+}
+
 // test hook: the matrix-core phase alone on tiles of 1024 elements (grid = tiles, 512 threads), in place
 __global__ __launch_bounds__(512) void k_blk16_apply(Fe256* __restrict__ data, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc) {
     __shared__ Fe256 tile[Blk16::kSub];

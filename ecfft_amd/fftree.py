@@ -31,7 +31,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
            "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z", "ecfft_build_exit_shard",
-           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_test_fail_next_collective", "ecfft_selftest_blk16", "ecfft_selftest_blk16_small", "ecfft_comm_abort", "ecfft_test_fail_build_rank", "ecfft_comm_init_projection"]
+           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_test_fail_next_collective", "ecfft_selftest_blk16", "ecfft_selftest_blk16_small", "ecfft_comm_abort", "ecfft_test_fail_build_rank", "ecfft_comm_init_projection", "ecfft_selftest_blk32", "ecfft_ctx_low_map"]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -117,6 +117,8 @@ def lib():
         L.ecfft_test_fail_build_rank.restype, L.ecfft_test_fail_build_rank.argtypes = ci, [ci]
         L.ecfft_selftest_blk16.restype, L.ecfft_selftest_blk16.argtypes = ci, [vp, vp, vp, sz, ci]
         L.ecfft_selftest_blk16_small.restype, L.ecfft_selftest_blk16_small.argtypes = ci, [vp, vp, vp, sz, ci, ci]
+        L.ecfft_selftest_blk32.restype, L.ecfft_selftest_blk32.argtypes = ci, [vp, vp, vp, sz, ci]
+        L.ecfft_ctx_low_map.restype, L.ecfft_ctx_low_map.argtypes = ci, [vp, ci]
         L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
         L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
@@ -424,6 +426,10 @@ class FFTree:
         return self._sharded(lib().ecfft_exit_sharded, comm, y_block, n)
 
     # ---- benchmarking aid -------------------------------------------------------------------
+    def low_map(self, direction):
+        """32 / 16 / 0: the composite map the 1024-element low-level kernels run for the lowest ENTER (0) / EXIT (1) levels"""
+        return lib().ecfft_ctx_low_map(self._h, int(direction))
+
     def profile(self, on):
         _check(lib().ecfft_profile_enable(self._h, int(on)))
 

@@ -276,6 +276,12 @@ int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t
  * lane (k_exit_low<8,128>'s low16)   3: 128-element arrays = 8 blocks, 2 waves, element in registers (k_exit_low<8,128>'s half-tiles)
  * 4: 256-element arrays, 4 waves, element in registers (k_stages_row256, k_enter_low<8,256>'s EXTEND cores).  n: a multiple of 256. */
 int ecfft_selftest_blk16_small(const void* matrix256, const void* x, void* out, size_t n, int mode, int device);
+/* ... the 32-point form (round 4: the five lowest ENTER / EXIT levels of the 1024-element low-level kernels as one map): matrix1024 =
+ * 32 x 32 plain residues, row-major [output][input]; every aligned block of 32 of x is mapped; n a multiple of 1024. */
+int ecfft_selftest_blk32(const void* matrix1024, const void* x, void* out, size_t n, int device);
+/* measurement / test hook: which composite map the context's 1024-element low-level kernels run for the lowest levels of ENTER
+ * (dir 0) / EXIT (dir 1): 32 = levels 1..5, 16 = levels 1..4, 0 = level code (secp256k1 only; A/B: ECFFT_LOW32, ECFFT_NO_LOW16) */
+int ecfft_ctx_low_map(const ecfft_ctx* ctx, int dir);
 
 /* Measurement hook: field multiplies per second of the butterfly kernels' table multiply run as a bare dependent chain
  * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot

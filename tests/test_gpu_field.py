@@ -193,3 +193,50 @@ def test_blk16_matrix_core_map_random_and_targeted_outputs(mode):
         assert got == want
         for k, tgt in enumerate(targets):
             assert got[16 * k] == tgt
+
+
+def _blk32(T, xs):
+    """ecfft_selftest_blk32: T = 32 x 32 ints, xs = ints (multiple of 1024) -> ints"""
+    from ecfft_amd import fftree as FT
+    m = pack256([T[o][i] for o in range(32) for i in range(32)])
+    x = pack256(xs)
+    out = np.zeros_like(x)
+    assert FT.lib().ecfft_selftest_blk32(m.ctypes.data, x.ctypes.data, out.ctypes.data, len(xs), 0) == 0
+    return unpack256(out)
+
+
+def test_blk32_matrix_core_map_directed_and_random():
+    """round 4: the 32-point form (the five lowest ENTER / EXIT levels of the 1024-element low-level kernels as one map,
+    Blk16::phase32): identity / -1 / all-ones maps on edge operands (carry-out and canonicalisation branches of the normalisation),
+    constants at the signed-digit recoding threshold, random maps against big-int arithmetic and outputs solved for 0, 1, p - 1"""
+    rnd = random.Random(32)
+    edge = [0, 1, 2, C - 1, C, C + 1, 2**32, 2**50, 2**51, 2**64, 2**128, 2**255, P256 - 1, P256 - 2, P256 - C, P256 - C - 1, P256 // 2,
+            0x7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F, 0x8080808080808080808080808080808080808080808080808080808080808080 % P256]
+    xs = (edge * 54)[:1024]
+    xs[512:] = [rnd.randrange(P256) for _ in range(512)]
+    ident = [[1 if o == i else 0 for i in range(32)] for o in range(32)]
+    assert _blk32(ident, xs) == xs
+    neg = [[P256 - 1 if o == i else 0 for i in range(32)] for o in range(32)]
+    assert _blk32(neg, xs) == [(-v) % P256 for v in xs]
+    ones = [[1] * 32 for _ in range(32)]
+    want = []
+    for b in range(0, 1024, 32):
+        want += [sum(xs[b:b + 32]) % P256] * 32
+    assert _blk32(ones, xs) == want
+    thr = 0x7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F7F
+    row = [thr, thr + 1, thr - 1, P256 - thr, 2**255, 2**255 - 1, P256 - 2**255, 255, 256, 2**248, 2**248 - 1, P256 - 256, C, P256 - C, 3, P256 - 3] * 2
+    for Tm in ([[row[(o + i) % 32] for i in range(32)] for o in range(32)], [[rnd.randrange(P256) for _ in range(32)] for _ in range(32)]):
+        xs2 = [rnd.randrange(P256) for _ in range(2048)]
+        inv00 = pow(Tm[0][0], -1, P256)
+        targets = [0, 1, P256 - 1, P256 - rnd.randrange(1, 2**40), rnd.randrange(2**40), C, C - 1, P256 - C]
+        for k, tgt in enumerate(targets):
+            b = 32 * k
+            rest = sum(Tm[0][i] * xs2[b + i] for i in range(1, 32)) % P256
+            xs2[b] = (tgt - rest) * inv00 % P256
+        got = _blk32(Tm, xs2)
+        want = []
+        for b in range(0, 2048, 32):
+            want += [sum(Tm[o][i] * xs2[b + i] for i in range(32)) % P256 for o in range(32)]
+        assert got == want
+        for k, tgt in enumerate(targets):
+            assert got[32 * k] == tgt

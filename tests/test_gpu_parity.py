@@ -491,10 +491,14 @@ def test_low16_maps_equal_the_level_code(gpu, monkeypatch):
     operand form is sensitive to, and on data that is non-zero in ONE position of each 16-block (every column of both maps on its own)."""
     n = 1 << 18
     P = gpu.FIELDS["secp256k1"]
+    monkeypatch.setenv("ECFFT_LOW32", "3")                                       # round 4: levels 1..5 as one 32-point map (built, bit-exact, not faster: off by default)
     t_map = P.build_fftree(n)
+    monkeypatch.delenv("ECFFT_LOW32")
     monkeypatch.setenv("ECFFT_NO_LOW16", "1")
     t_lvl = P.build_fftree(n)
     monkeypatch.delenv("ECFFT_NO_LOW16")
+    t_16 = P.build_fftree(n)                                                     # the default: low16
+    assert (t_map.low_map(0), t_map.low_map(1)) == (32, 32) and (t_16.low_map(0), t_16.low_map(1)) == (16, 16) and t_lvl.low_map(1) == 0
     rng = np.random.default_rng(0x10316)
     rand = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); rand[:, 3] >>= np.uint64(1)
     pat = np.zeros((n, 4), dtype=np.uint64)
@@ -507,8 +511,11 @@ def test_low16_maps_equal_the_level_code(gpu, monkeypatch):
     pos = np.arange(n)
     sel = (pos % 16) == ((pos // 16) % 16)                                       # block b carries its value in position b mod 16
     cols[sel] = rand[sel]
-    for data in (rand, pat, pm1, cols):
+    cols32 = np.zeros((n, 4), dtype=np.uint64)
+    sel = (pos % 32) == ((pos // 32) % 32)                                       # ... of each 32-block (every column of the low32 maps on its own)
+    cols32[sel] = rand[sel]
+    for data in (rand, pat, pm1, cols, cols32):
         ev = t_map.enter(data)
-        assert np.array_equal(ev, t_lvl.enter(data))
-        assert np.array_equal(t_map.exit(data), t_lvl.exit(data))
+        assert np.array_equal(ev, t_lvl.enter(data)) and np.array_equal(ev, t_16.enter(data))
+        assert np.array_equal(t_map.exit(data), t_lvl.exit(data)) and np.array_equal(t_map.exit(data), t_16.exit(data))
         assert np.array_equal(t_map.exit(ev), data)
