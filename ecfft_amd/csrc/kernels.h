@@ -153,6 +153,12 @@ __device__ __forceinline__ typename F::elem io_mid(const IoDesc<F>& io, size_t p
 // generic, and generic (flat_load) accesses count against the LDS counter as well as the vector-memory one.
 template <class TE>
 __device__ __forceinline__ TE ldt(const TE* __restrict__ base, uint32_t idx) {
+#ifdef ECFFT_EXP_NO_TABLE_LOADS      // experiment: constants made up in registers (no VMEM) — the bound of what free table loads could reach
+    { TE r; uint32_t* w = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+      for (int k = 0; k < (int)(sizeof(TE) / 4); ++k) w[k] = (idx + 0x01010101u * (uint32_t)k) >> (sizeof(TE) == 4 ? 2 : 1);
+      return r; }
+#endif
     typedef const __attribute__((address_space(1))) char* gchar;
     if constexpr (sizeof(TE) == 4) {
         typedef const __attribute__((address_space(1))) TE* gte;
@@ -179,6 +185,11 @@ __device__ __forceinline__ TE ldt(const TE* __restrict__ base, uint32_t idx) {
 // Preconditions checked by vio_ok(): e >= 4, 16-byte aligned pointers, strides as produced by the level drivers.
 // ---------------------------------------------------------------------------------------------
 struct Quad { uint32_t v[4]; };
+#ifdef ECFFT_EXP_TILE_IO_L2       // experiment: every tile load / store of the 4-byte vector paths lands in one 64 KiB window (cache resident):
+#define ECFFT_DPOS(p) ((p) & (size_t)0x3FFF)      // the work stays, the HBM latency and bandwidth go — what a perfect prefetch ring could reach
+#else
+#define ECFFT_DPOS(p) (p)
+#endif
 __device__ __forceinline__ Quad ldq(const uint32_t* p) { uint4 t = *reinterpret_cast<const uint4*>(p); return Quad{{t.x, t.y, t.z, t.w}}; }
 __device__ __forceinline__ void stq(uint32_t* p, const Quad& q) { *reinterpret_cast<uint4*>(p) = make_uint4(q.v[0], q.v[1], q.v[2], q.v[3]); }
 // four consecutive 4-byte table entries starting at entry idx (16-byte aligned), uniform base pointer in the GLOBAL address space + 32-bit byte offset (see ldt below)
@@ -212,7 +223,7 @@ __device__ __forceinline__ void vio_load(const IoDesc<F>& io, size_t emask, type
     const uint32_t tid = tid0;   // callers that split a tile into batches pass tid + batch*NQ*BLK (quad c of the batch = index 4*(tid + c*BLK))
     Quad d[NQ], t[NQ];
 #pragma unroll
-    for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); d[c] = ldq_strided(io.src + (size_t)io.src_stride * pos, io.src_stride, io.src_off); }
+    for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); d[c] = ldq_strided(io.src + (size_t)io.src_stride * ECFFT_DPOS(pos), io.src_stride, io.src_off); }
     if (io.ld_mode == LD_SCALE) {
 #pragma unroll
         for (int c = 0; c < NQ; ++c) { const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK)); t[c] = ldq_tab(io.ld_tbl, (uint32_t)(pos & emask)); }
@@ -240,7 +251,7 @@ __device__ __forceinline__ void vio_store(const IoDesc<F>& io, uint32_t log_e, c
         for (int c = 0; c < NQ; ++c) {
             const size_t pos = pos_of(4u * (tid + (uint32_t)c * BLK));
             b[c] = ldq_tab(io.st_b, (uint32_t)(pos & emask));
-            y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * pos, io.aux_stride, io.aux_off);
+            y[c] = ldq_strided(io.aux + (size_t)io.aux_stride * ECFFT_DPOS(pos), io.aux_stride, io.aux_off);
         }
     }
 #pragma unroll
@@ -256,10 +267,10 @@ __device__ __forceinline__ void vio_store(const IoDesc<F>& io, uint32_t log_e, c
         }
         if (m == ST_EXIT_SPLIT) {
             const size_t bs = (pos >> log_e) << (log_e + 1), i = pos & emask;
-            stq(io.dst + bs + i, r); stq(io.dst + bs + e + i, r2);
+            stq(io.dst + ECFFT_DPOS(bs + i), r); stq(io.dst + ECFFT_DPOS(bs + e + i), r2);
         } else {
-            stq(io.dst + pos, r);
-            if (m == ST_AXPBY && io.aux_out) stq(io.aux_out + pos, r);
+            stq(io.dst + ECFFT_DPOS(pos), r);
+            if (m == ST_AXPBY && io.aux_out) stq(io.aux_out + ECFFT_DPOS(pos), r);
         }
     }
 }
@@ -310,7 +321,7 @@ __device__ __forceinline__ void vio_enter_store(const typename F::elem* tile, co
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
         uint32_t ju, jv; size_t i, bb; idx(cbase + c, ju, jv, i, bb);
-        u0[c] = ldq(src + bb + i); v0[c] = ldq(src + bb + e + i);
+        u0[c] = ldq(src + ECFFT_DPOS(bb + i)); v0[c] = ldq(src + ECFFT_DPOS(bb + e + i));
         tx[c] = ldq_tab(xe, (uint32_t)i); tw[c] = ldq_tab(w1, (uint32_t)i); twx[c] = ldq_tab(w1x, (uint32_t)i);
         U[c] = ldq(tile + ju); V[c] = ldq(tile + jv);
     }
@@ -324,7 +335,7 @@ __device__ __forceinline__ void vio_enter_store(const typename F::elem* tile, co
             const uint32_t od = F::canon(F::tmul_add(twx[c].v[k], V[c].v[k], F::tmul(tw[c].v[k], U[c].v[k])));
             if (k < 2) { lo.v[2 * k] = ev; lo.v[2 * k + 1] = od; } else { hi.v[2 * (k - 2)] = ev; hi.v[2 * (k - 2) + 1] = od; }
         }
-        stq(dst + bb + 2 * i, lo); stq(dst + bb + 2 * i + 4, hi);
+        stq(dst + ECFFT_DPOS(bb + 2 * i), lo); stq(dst + ECFFT_DPOS(bb + 2 * i + 4), hi);
     }
 }
 
@@ -617,13 +628,17 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     if constexpr (kFast) vio = vio_ok<F>(io, log_e);
     if constexpr (kFast) {
         if (vio) {
+#ifndef ECFFT_EXP_NO_TILE_IO      // experiment (tools/experiments/README): compute only — the bound of what perfect tile prefetch could reach
 #pragma unroll 1
             for (uint32_t b = 0; b < (uint32_t)kNQ / 4; ++b) vio_load<F, 4, kBlockRow>(io, emask, tile, [=](uint32_t j) { return base + j; }, tid + b * 4u * kBlockRow);
+#endif
         }
     }
     if (!vio) {
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll
         for (uint32_t j = tid; j < T; j += kBlockRow) tile[j] = io_load<F>(io, base + j, emask);
+#endif
     }
     __syncthreads();
     const uint32_t npairs = T >> 1;
@@ -726,6 +741,9 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         if constexpr (kFast) {
             auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
             if (log_e >= 2 && al(io.aux) && al(io.dst) && al(io.st_a) && al(io.st_b) && al(io.st_c)) {
+#ifdef ECFFT_EXP_NO_TILE_IO
+                return;
+#endif
 #pragma unroll 1
                 for (int cb = 0; cb < kNQ / 2; cb += 2)
                     vio_enter_store<F, 2>(tile, io.aux, io.dst, io.st_a, io.st_c, io.st_b, e, [=](int c, uint32_t& ju, uint32_t& jv, size_t& i, size_t& bb) {
@@ -735,6 +753,9 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                 return;
             }
         }
+#ifdef ECFFT_EXP_NO_TILE_IO
+        return;
+#endif
         for (uint32_t g = tid; g < npairs; g += kBlockRow) {
             const uint32_t i = g & (uint32_t)emask, lb = (g >> log_e) << (log_e + 1);
             const size_t bb = base + lb;
@@ -748,13 +769,17 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     }
     if constexpr (kFast) {
         if (vio) {
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll 1
             for (uint32_t b = 0; b < (uint32_t)kNQ / 4; ++b) vio_store<F, 4, kBlockRow>(io, log_e, tile, [=](uint32_t j) { return base + j; }, tid + b * 4u * kBlockRow);
+#endif
             return;
         }
     }
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockRow) io_store<F>(io, base + j, log_e, tile[j]);
+#endif
 }
 
 // forward declaration (defined with the low-level kernels below)
@@ -999,29 +1024,37 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col(IoDes
         if (log_v && !vio) return;                                   // host only pairs spans on the vector path (never taken)
         if (vio) {
             // paired spans: two batches of four quads per thread (one batch of eight needs > 128 VGPRs and spills)
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll 1
             for (uint32_t b = 0; b < (1u << log_v); ++b) vio_load<F, 4, kBlockLds>(io, emask, tile, pos_of, tid + b * 4u * kBlockLds);
+#endif
             __syncthreads();
             col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1u << log_v, nullptr);
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll 1
             for (uint32_t b = 0; b < (1u << log_v); ++b) vio_store<F, 4, kBlockLds>(io, log_e, tile, pos_of, tid + b * 4u * kBlockLds);
+#endif
             return;
         }
     }
     if (!vio) {
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll
         for (uint32_t j = tid; j < T; j += kBlockLds) {
             uint32_t r = j >> log_c, cc = j & (C - 1);
             tile[r * col_row_stride<E>(C) + cc] = io_load<F>(io, B + ((size_t)r << log_hs) + cc, emask);
         }
+#endif
     }
     __syncthreads();
     col_stages<F, DECOMPOSE>(tile, ta, tb, R, log_c, log_hs, c0, e, tid, 1, DECOMPOSE ? tc : nullptr);
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io_store<F>(io, B + ((size_t)r << log_hs) + cc, log_e, tile[r * col_row_stride<E>(C) + cc]);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1072,22 +1105,28 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
             return;
         }
     }
+#ifndef ECFFT_EXP_NO_TILE_IO
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         tile[r * col_row_stride<E>(C) + cc] = io.src[B + ((size_t)r << log_hs) + cc];
     }
+#endif
     __syncthreads();
     col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid);
+#ifndef ECFFT_EXP_NO_MID
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         { const uint32_t q = r * col_row_stride<E>(C) + cc; tile[q] = io_mid<F>(io, B + ((size_t)r << log_hs) + cc, emask, tile[q]); }
     }
+#endif
     __syncthreads();
     col_stages<F, true>(tile, np0, dinv, R, log_c, log_hs, c0, e, tid, 1, c0t);
+#ifndef ECFFT_EXP_NO_TILE_IO
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
         io.dst[B + ((size_t)r << log_hs) + cc] = F::canon(tile[r * col_row_stride<E>(C) + cc]);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1123,16 +1162,21 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_enter
         auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         vio = T == kBlockLds * 32 && log_c >= 2 && al(work) && al(src) && al(dst) && al(xe) && al(w1) && al(w1x);
         if (vio) {
+#ifndef ECFFT_EXP_NO_TILE_IO
             Quad d[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const uint32_t j = 4u * (tid + (uint32_t)c * kBlockLds), r = j >> log_c, cc = j & (C - 1);
-                d[c] = ldq(work + B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc);
+                d[c] = ldq(work + ECFFT_DPOS(B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc));
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) stq(tile + 4u * (tid + (uint32_t)c * kBlockLds), d[c]);
+#endif
             __syncthreads();
             col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 2);
+#ifdef ECFFT_EXP_NO_TILE_IO
+            return;
+#endif
             const size_t bb0 = b << (log_e + 1);
 #pragma unroll 1
             for (int cb = 0; cb < 4; cb += 2)
@@ -1143,14 +1187,19 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_enter
             return;
         }
     }
+#ifndef ECFFT_EXP_NO_TILE_IO
 #pragma unroll
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         const uint32_t r = j >> log_c, cc = j & (C - 1);            // r < 2^(R+1): r >> R selects the vector
         tile[r * RS + cc] = work[B + ((size_t)(r >> R) << log_e) + ((size_t)(r & ((1u << R) - 1)) << log_hs) + cc];
     }
+#endif
     __syncthreads();
     // the U rows and the V rows are two independent column tiles that read the same table entries
     col_stages<F, false>(tile, p0, p1, R, log_c, log_hs, c0, e, tid, 2);
+#ifdef ECFFT_EXP_NO_TILE_IO
+    return;
+#endif
 #pragma unroll
     for (uint32_t j = tid; j < (T >> 1); j += kBlockLds) {
         const uint32_t r = j >> log_c, cc = j & (C - 1);
