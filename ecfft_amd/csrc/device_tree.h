@@ -1203,6 +1203,35 @@ public:
         E *cur = nullptr, *e0 = nullptr, *e1 = nullptr, *t0 = nullptr, *h0 = nullptr, *h1 = nullptr, *A = nullptr, *B = nullptr, *x0 = nullptr, *x1 = nullptr, *Rb = nullptr;
         E *blk = nullptr, *Y = nullptr;
         const bool sh = shard_mode();
+        // round 4, FULL contexts and transforms of at most 2^gather_max_log_: EVERY top level redundantly.  The projection
+        // (tools/split_project.py) shows the split top levels latency bound at these sizes — a split level of an n = 2^20 EXIT costs a
+        // rank ~0.45 ms in ~30 small launches plus nine exchanges, the same level on the WHOLE block ~0.2 ms at full-chip efficiency.
+        // So: ONE all-gather of the input, then every rank walks its own path down the tree — level Q on the Q c block that contains
+        // its chunk (single-GPU fused passes on the full tables), keep the half that contains the chunk, level Q / 2 on that, ...
+        // — less than twice the top level's arithmetic in total, no exchange after the first.  Needs the whole chain on every GPU
+        // (a full context; EXIT-shard contexts keep the split levels — their point is a transform whose tables exceed one GPU, and at
+        // those sizes a split level is throughput bound and wins).
+        if (!sh && ilog2(n) <= gather_max_log_ && trees_.size() > ilog2(n)) {
+            E *ga = nullptr, *gb = nullptr;
+            if (!collective_prepare(tr, 3, n, 2, s, [&] { ga = temp(n); gb = temp(n); if (!ensure_scratch(n)) throw DeviceAllocError(); })) return false;
+            P2P snd[64], rcv[64];
+            if (P > 64) { temps_done(); return false; }
+            for (size_t q = 0; q < P; ++q) { snd[q] = {(int)q, const_cast<E*>(in), c * sizeof(E)}; rcv[q] = {(int)q, ga + q * c, c * sizeof(E)}; }
+            bool ok = tr.exchange(snd, (int)P, rcv, (int)P, s);
+            E *src = ga, *dst = gb; size_t off = 0;                         // the current block starts at src + off
+            for (size_t Q = P; ok && Q >= 2; Q /= 2) {
+                const size_t m = c * Q;
+                const size_t blk0 = ((size_t)tr.rank / Q) * Q * c;           // global position of the block of Q c that contains this rank's chunk
+                if (Q == P) off = blk0;                                      // (0: the whole vector)
+                exit_levels(src + off, dst, m, 1, s, scratch_, ilog2(m), ilog2(m));       // dst[0, m) = [u0 | v0] of the block
+                off = (((size_t)tr.rank / (Q / 2)) & 1) * (m / 2);            // the half that contains the chunk
+                E* t = src; src = dst; dst = t;
+            }
+            if (ok) ok = exit(src + off, out, c, 1, s);
+            ok = ok && hipGetLastError() == hipSuccess;
+            temps_done();
+            return ok;
+        }
         // round 4: the level of the PAIRS (Q = 2, blocks of 2c) runs redundantly on both ranks of a pair: ONE exchange hands each rank
         // its partner's (e0, e1) share, the level itself is the single-GPU EXIT level of the 2c block on the full tree T_2c (fused
         // passes, no pack / unpack, no cyclic passes), and each rank keeps its own half of [u0 | v0] — which IS its chunk for the
@@ -2054,6 +2083,8 @@ private:
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
     Tree pair_full_{}; bool have_pair_full_ = false;                    // EXIT-shard contexts: the full tree T_2c (c = n / world) of the redundant pair level
+    // full contexts: split EXITs of at most 2^this run every top level redundantly after one all-gather (0: never) — api_exit_split
+    unsigned gather_max_log_ = getenv("ECFFT_SPLIT_GATHER_MAX_LOG") ? (unsigned)atoi(getenv("ECFFT_SPLIT_GATHER_MAX_LOG")) : 21u;
     bool q2_split_ = getenv("ECFFT_SPLIT_Q2_SPLIT") != nullptr;        // A/B switch (full contexts): the pair level of a split EXIT as four split EXTENDs
     bool col256_off_ = getenv("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
     bool row256_off_ = getenv("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)

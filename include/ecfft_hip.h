@@ -140,7 +140,9 @@ int ecfft_extend_local_block(ecfft_ctx* ctx, void* buf, size_t e, int moiety, un
  * Exchanges (grouped send / receive calls) per transform: EXTEND 4 (2 per cyclic side saved, ecfft_extend_sharded_layout); ENTER
  * 3 per top level + 1 (Q = 2: 1); EXIT 1 + 9 per top level above the pairs + 1 — inside a level every vector stays cyclic over its
  * group; the level of the PAIRS of ranks (blocks of 2 len / world) runs redundantly on both ranks of a pair from one exchange
- * (round 4), so EXIT takes 2 / 11 / 20 exchanges at world = 2 / 4 / 8 (before: 10 / 19 / 28). */
+ * (round 4), so EXIT takes 2 / 11 / 20 exchanges at world = 2 / 4 / 8 (before: 10 / 19 / 28).  A FULL context (tables replicated) splits an EXIT of at
+ * most 2^21 (ECFFT_SPLIT_GATHER_MAX_LOG) differently: one all-gather, then every top level redundantly on the block that contains the
+ * rank's chunk — ONE exchange per EXIT (the split top levels are latency bound at such sizes, tools/split_project.py). */
 typedef struct ecfft_comm ecfft_comm;
 #define ECFFT_COMM_ID_BYTES 128
 /* n sends and n receives of device buffers that must progress together; return 0 on success */

@@ -453,25 +453,28 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
     torch.cuda.synchronize()
     logp = P.bit_length() - 1
     counts = {}
-    for mode in ("full", "full-split-pairs", "shard"):
+    for mode in ("full-gather", "full", "full-split-pairs", "shard"):
+        # full-gather: the default of a FULL context at these sizes — one all-gather, then every top level redundantly
+        if mode in ("full", "full-split-pairs"):
+            monkeypatch.setenv("ECFFT_SPLIT_GATHER_MAX_LOG", "0")
         if mode == "full-split-pairs":
             monkeypatch.setenv("ECFFT_SPLIT_Q2_SPLIT", "1")
         got, nx = {}, {}
 
         def body(rank, make_comm):
             comm = make_comm()
-            ctx = F.build_exit_shard(n, comm) if mode == "shard" else F.build_fftree(n)
+            ctx = F.build_exit_shard(n, comm) if mode == "shard" else F.build_fftree(n)     # the environment is read when a context is built
             mine = x[rank * c:(rank + 1) * c].clone()
             comm.stats(True)
             got[rank] = ctx.exit_sharded(comm, mine, n)
             nx[rank] = comm.stats()["exchanges"]
 
         _thread_ranks(P, body)
-        if mode == "full-split-pairs":
-            monkeypatch.delenv("ECFFT_SPLIT_Q2_SPLIT")
+        monkeypatch.delenv("ECFFT_SPLIT_Q2_SPLIT", raising=False); monkeypatch.delenv("ECFFT_SPLIT_GATHER_MAX_LOG", raising=False)
         for rank in range(P):
             assert torch.equal(got[rank], want[rank * c:(rank + 1) * c]), (mode, rank)
         counts[mode] = nx[0]
+    assert counts["full-gather"] == 1
     assert counts["full-split-pairs"] == 1 + 9 * logp
     assert counts["full"] == counts["shard"] == 1 + 9 * (logp - 1) + 1
     assert counts["full"] <= 0.8 * counts["full-split-pairs"] or logp > 2          # >= 20 % fewer exchange latencies (P = 2: 10 -> 2, P = 4: 19 -> 11, P = 8: 28 -> 20)

@@ -57,6 +57,7 @@ print(f"projection: {delay:.0f} us per exchange with a remote peer; link model {
 print("  P | per-rank compute ms (ENTER + EXIT) | launches | exchanges (ENTER + EXIT) | MB sent/rank | T(delay) ms | exposed ms | exposed/exchange us | "
       "T(delay + bytes/bw) ms | speed-up vs 1 GPU at delay / at delay+bw | bit-exact")
 rows = []
+full_rows = []
 for P in worlds:
     c = n // P
     board, bar = {}, threading.Barrier(P)
@@ -125,5 +126,23 @@ for P in worlds:
           f"{single / res['td']:.2f}x / {single / res['tb']:.2f}x | {exact}")
     del esh, xsh, keep
     torch.cuda.empty_cache()
+    # FULL context (tables replicated): the split EXIT is one all-gather + every top level redundantly (api_exit_split, n <= 2^21)
+    fullc = F.build_fftree(n)
+    resf = {}
+    for tag, d_us, bw in (("t0", 0.0, 0.0), ("td", delay, 0.0), ("tb", delay, gbps)):
+        comm = D.Comm.projection(P, 0, 0, d_us, bw)
+        runx = lambda: fullc.exit_sharded(comm, mine, n)      # noqa: E731
+        runx(); runx()
+        resf[tag] = med_ms(runx)
+        if tag == "t0":
+            comm.stats(True); runx(); stf = comm.stats(); comm.stats(False)
+        del comm
+    full_rows.append((P, resf, stf))
+    del fullc
+    torch.cuda.empty_cache()
 print("(compute = rank 0's whole stream with zero-cost exchanges: local levels on the 2^%d chunk + its share of the log2 P top levels + pack / unpack;" % (log_n,))
 print(" exchanges with world = P include the self pieces of the group all-to-alls; 'exposed' is measured on the stream, not computed)")
+print("FULL contexts (tables replicated; default for n <= 2^21): split EXIT = one all-gather, then every top level redundantly on the block that contains the rank's chunk")
+print("  P | EXIT per-rank compute ms | exchanges | MB sent/rank | EXIT T(delay) ms | EXIT T(delay + bytes/bw) ms | vs single-GPU EXIT %.3f ms" % single_exit)
+for P, r, st in full_rows:
+    print(f"  {P} | {r['t0']:.3f} | {st['exchanges']:.0f} | {st['bytes_sent'] / 1e6:.1f} | {r['td']:.3f} | {r['tb']:.3f} | {single_exit / r['td']:.2f}x / {single_exit / r['tb']:.2f}x")
