@@ -466,8 +466,15 @@ def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_
     if world > 1:
         # sharded contexts: the chain up to n/world + this rank's share of the top trees (the EXIT one is a collective build)
         t_enter = F.build_enter_shard(n, world, rank, device=local_rank)
-        t_exit = F.build_exit_shard(n, comm, device=local_rank)
-        tables = "sharded: chain up to n/world + the rank's share of the log2(world) top trees (ecfft_build_enter_shard / ecfft_build_exit_shard)"
+        if log_n <= 21 and os.environ.get("ECFFT_BENCH_SPLIT_EXIT", "gather") != "shard":
+            # round 4: at these sizes the split top levels of an EXIT are latency bound (tools/split_project.py), so the EXIT runs on a
+            # FULL context (1.8 GiB of tables at 2^20, replicated): one all-gather, then every top level redundantly — 1 exchange
+            t_exit = F.build_fftree(n, device=local_rank)
+            tables = ("ENTER sharded: chain up to n/world + the rank's share of the log2(world) top trees (ecfft_build_enter_shard); "
+                      "EXIT full chain replicated: one all-gather, top levels redundant on the block of the rank's chunk (n <= 2^21)")
+        else:
+            t_exit = F.build_exit_shard(n, comm, device=local_rank)
+            tables = "sharded: chain up to n/world + the rank's share of the log2(world) top trees (ecfft_build_enter_shard / ecfft_build_exit_shard)"
     else:
         t_enter = t_exit = F.build_fftree(n, device=local_rank)
         tables = "full chain (world = 1)"
