@@ -330,9 +330,54 @@ def enter_sharded(ops, x_block, n, groups):
     return out.reshape(shape)
 
 
-def exit_sharded(ops, y_block, n, groups):
+def exit_level_block(ops, blk, m):
+    """ONE level of FFTree::exit (src/fftree.rs:206-224) on a whole block of m evaluations in natural order held by ONE rank:
+    returns [u0 | v0] (m/2 each).  The redundant top levels of the split EXIT (DeviceChain::api_exit_split, round 4) run this —
+    there as the single-GPU fused passes, here with the same table steps as the split level at Q = 1."""
+    limbs = blk.shape[1]
+    e = m // 2
+    pairs = blk.reshape(e, 2 * limbs)
+    e0, e1 = pairs[:, :limbs].contiguous(), pairs[:, limbs:].contiguous()
+
+    def redc(x0, x1):
+        t0 = ops.table_fma(x0, None, m, TBL_XNN_S_INV, 0, 2, 0)
+        g1 = ops.extend_local(t0, S1)
+        h1 = ops.table_fma(ops.table_fma(g1, x1, m, TBL_XNN_S, 1, 2, 2), None, m, TBL_Z0_INV_S1, 0, 1, 0)
+        return ops.extend_local(h1, S0), h1
+    h0, h1 = redc(e0, e1)
+    u0, _ = redc(ops.table_fma(h0, None, m, TBL_Z0Z0, 0, 2, 0), ops.table_fma(h1, None, m, TBL_Z0Z0, 1, 2, 0))
+    v0 = ops.table_fma(u0, e0, m, TBL_XNN_S_INV, 0, 2, 3)
+    return torch.cat([u0, v0]).contiguous()
+
+
+def exit_sharded_gather(ops, y_block, n):
+    """FFTree::exit of n evaluations held block-distributed, the form a FULL context uses for n <= 2^21 (api_exit_split, round 4):
+    ONE all-gather, then every rank walks its own path down the tree — level Q on the block of Q c evaluations that contains its
+    chunk, keep the half that contains the chunk — and finishes with the local EXIT of its chunk.  No exchange after the first."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    c = y_block.shape[0]
+    assert c * world == n
+    shape = y_block.shape
+    mine = y_block.reshape(c, -1).contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, mine)
+    else:
+        parts = [mine]
+    blk = torch.cat(parts).contiguous()                        # the block of Q c evaluations that contains the chunk, Q = world
+    Q = world
+    while Q >= 2:
+        m = c * Q
+        out = exit_level_block(ops, blk, m)                    # [u0 | v0]
+        half = (rank // (Q // 2)) & 1
+        blk = out[half * (m // 2):(half + 1) * (m // 2)].contiguous()
+        Q //= 2
+    return ops.exit_local(blk).reshape(shape)
+
+
+def exit_sharded(ops, y_block, n, groups, pair_local=True):
     """FFTree::exit (src/fftree.rs:227-230) of n evaluations held block-distributed; returns this rank's block of the
-    coefficients.  The MODEL of DeviceChain::api_exit_split: one all-to-all turns the block into (e0, e1) cyclic over all
+    coefficients.  The MODEL of DeviceChain::api_exit_split (pair_local: the pair level redundantly, as the C++ does since round 4): one all-to-all turns the block into (e0, e1) cyclic over all
     ranks; inside a level every length-m/2 vector is cyclic over the group of Q ranks (entry j = position j*Q + a), the
     tables are read at those positions, the four EXTENDs run cyclic-in / cyclic-out, and one exchange re-distributes
     (u0 | v0): rank a's whole u0 share is the even (a even) or odd (a odd) half of what sub-rank a/2 of the lower half-group
@@ -355,6 +400,16 @@ def exit_sharded(ops, y_block, n, groups):
         a = rank - base
         m, e = c * Q, c * Q // 2
         G = groups[Q]
+        if Q == 2 and pair_local:
+            # round 4: the level of the PAIRS runs redundantly on both ranks: one exchange hands each rank its partner's (e0, e1)
+            # share (positions i = 2j + partner), the level is the whole-block level, each rank keeps its half of [u0 | v0]
+            mine2 = torch.cat([e0, e1], dim=1).contiguous()                       # row j = (e0, e1) at i = 2j + a
+            both = [torch.empty_like(mine2) for _ in range(2)]
+            dist.all_gather(both, mine2, group=G)
+            blk = torch.stack([both[0], both[1]], dim=1).reshape(2 * c, limbs).contiguous()   # row 2i + par, i = 2j + a'
+            out = exit_level_block(ops, blk, m)
+            cur = out[a * c:(a + 1) * c].contiguous()
+            return ops.exit_local(cur).reshape(shape)
 
         def redc(x0, x1):                                      # redc_impl with a = xnn_s, moiety S0 (:232-259), at positions j*Q + a
             t0 = ops.table_fma(x0, None, m, TBL_XNN_S_INV, 2 * a, 2 * Q, 0)

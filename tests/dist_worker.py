@@ -149,6 +149,12 @@ def main():
         r = ot.exit(x)
         got = D.exit_sharded(ops, mine, n, groups)
         ok = ok and np.array_equal(ops._np(got), r[rank * c:(rank + 1) * c])
+        # round 4: the same with every level split (the form before), and the gather form of full contexts (one all-gather, then
+        # every top level redundantly on the block that contains the rank's chunk)
+        got = D.exit_sharded(ops, mine, n, groups, pair_local=False)
+        ok = ok and np.array_equal(ops._np(got), r[rank * c:(rank + 1) * c])
+        got = D.exit_sharded_gather(ops, mine, n)
+        ok = ok and np.array_equal(ops._np(got), r[rank * c:(rank + 1) * c])
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
