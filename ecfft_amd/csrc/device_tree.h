@@ -1386,7 +1386,8 @@ public:
     // to shorten a sweep is to spread a tile's pairs over more CUs.  For 32-byte fields launches with < kSmallTiles tiles of
     // the default size use 4x smaller tiles: 256 elements, 128-thread low-level kernels, one wave per SIMD.
     static constexpr unsigned kLogLowSmall = 8, kBlockLowSmall = 128, kSmallTiles = 256;
-    static bool small_launch(size_t total) { return sizeof(E) == 32 && (total >> kLogLow) < kSmallTiles && total >= ((size_t)1 << kLogLowSmall); }
+    static unsigned small_tiles_max() { static const unsigned v = getenv("ECFFT_SMALL_TILES_MAX") ? (unsigned)atoi(getenv("ECFFT_SMALL_TILES_MAX")) : kSmallTiles; return v; }   // A/B knob
+    static bool small_launch(size_t total) { return sizeof(E) == 32 && (total >> kLogLow) < small_tiles_max() && total >= ((size_t)1 << kLogLowSmall); }
     unsigned log_low_for(size_t total) const { return small_launch(total) && !ef_small_off_ ? kLogLowSmall : kLogLow; }
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
