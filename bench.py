@@ -643,8 +643,12 @@ def build_roofline(args, F, n, classes, step_s, device):
         # a 1024-element phase = 512 MFMAs.  In an EXTEND it stands for 7 sweeps x 1024 multiplies (14 per MFMA, mfma_blk16.h); the
         # low16 phases of k_enter_low / k_exit_low (n/2 MFMAs each per transform, launches of >= 2^18 elements) stand for levels 1..4 =
         # 19 n resp. 34 n multiplies of executed_mul's closed forms (38 / 68 per MFMA)
-        low16 = n // 2 if (tot_mfma > 0 and n >= (1 << 18) and not os.environ.get("ECFFT_NO_LOW16") and args.field != "m31") else 0
-        on_mfma = 14.0 * max(tot_mfma - 2 * low16, 0.0) + (38.0 + 68.0) * low16
+        # round 4: launches of < 2^18 elements run 256-element tiles whose phase is 256 v_mfma_i32_16x16x64_i8 (7 multiplies per MFMA) and
+        # whose low16 phases are n MFMAs per transform; between 2^18 and 2^19 the two regimes mix and the split is approximate
+        small = n < (1 << 18)
+        low_on = tot_mfma > 0 and n >= (1 << 8) and not os.environ.get("ECFFT_NO_LOW16") and args.field != "m31"
+        low16 = (n if small else n // 2) if low_on else 0
+        on_mfma = (7.0 if small else 14.0) * max(tot_mfma - 2 * low16, 0.0) + ((19.0 + 34.0) * n if low_on else 0.0)
         valu_mul = max(xe_ + xx_ - on_mfma, 0.0)
         out["valu"] = {"executed_mul_per_step": xe_ + xx_, "of_which_on_matrix_cores": on_mfma, "valu_mul_per_step": valu_mul,
                        "achieved": valu_mul / step_s, "peak": max(ceil4, ceil8), "unit": "mul/s",
@@ -678,7 +682,7 @@ def build_roofline(args, F, n, classes, step_s, device):
                                    "note": "4 x SQ_ACTIVE_INST_VALU (quad-cycles the VALU was issuing) / (step time x measured shader clock x 1024 SIMDs)"}
             out["mfma"] = {"busy_frac": mbusy / simd_cycles, "SQ_VALU_MFMA_BUSY_CYCLES_per_step": mbusy,
                            "instructions_per_step": sum((cls_ctr.get(c["name"]) or {}).get("SQ_INSTS_VALU_MFMA_I8", 0.0) * c["launches"] / args.steps for c in live),
-                           "note": "v_mfma_i32_32x32x32_i8 of the innermost 16-point maps (mfma_blk16.h); the matrix pipe is a side channel here, "
+                           "note": "v_mfma_i32_32x32x32_i8 (1024-element tiles) / v_mfma_i32_16x16x64_i8 (256-element tiles of small launches) of the innermost 16-point maps (mfma_blk16.h); the matrix pipe is a side channel here, "
                                    "the integer VALU still binds"}
     except Exception:  # pragma: no cover
         pass

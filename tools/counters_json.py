@@ -27,7 +27,8 @@ def kernel_source_hash():
                 h.update(f.encode()); h.update(fh.read())
     return h.hexdigest()[:16]
 
-CLASSES = {"k_stages_lds": ["k_stages_lds<"], "k_stages_col": ["k_stages_col<", "k_stages_col_mid<", "k_stages_col_enter<"],
+CLASSES = {"k_stages_lds": ["k_stages_lds<", "k_stages_row256<"],
+           "k_stages_col": ["k_stages_col<", "k_stages_col_mid<", "k_stages_col_enter<", "k_stages_col256<", "k_stages_col_mid256<", "k_stages_col_enter256<"],
            "k_enter_low": ["k_enter_low<"], "k_exit_low": ["k_exit_low<"], "k_decompose_stage": ["k_decompose_stage<"],
            "k_recombine_stage": ["k_recombine_stage<"]}
 
