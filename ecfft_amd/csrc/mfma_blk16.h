@@ -464,9 +464,7 @@ struct Blk16 {
         uint4* lds = reinterpret_cast<uint4*>(sub);
         const uint32_t L = tid & 63, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), n = L & 31, h = L >> 5;
         const gchar ap = (gchar)(reinterpret_cast<const char*>(Amat)) + ((size_t)(4 * w) * NB32) * 1024 + L * 16;
-        auto ldA32 = [&](int oo, int i) { return *(gv4)(ap + ((size_t)oo * NB32 + (size_t)i) * 1024); };
         const char* lb = reinterpret_cast<const char*>(lds);
-        auto ldB = [&](int i) { const uint32_t c = 64u * n + 2u * (uint32_t)i + h; const uint4 b = *reinterpret_cast<const uint4*>(lb + 16u * ((c & ~15u) | ((c ^ n) & 15u))); v4i v = {(int)b.x, (int)b.y, (int)b.z, (int)b.w}; return v; };
         // two passes of two outputs each (two 32 x 32 accumulators): four at once need > 128 VGPRs next to the low-level kernels' other
         // registers and spill; the data operands are read from LDS again in the second pass
         E outz[2];
