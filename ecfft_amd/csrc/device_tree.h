@@ -1307,7 +1307,9 @@ public:
         unsigned ln = ilog2(n);
         if (count == 1 && ln >= kSplitMinLog && nside_ > 0) {
             int next_side = 0;
+            in_halves_ = true;
             enter_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
+            in_halves_ = false;
         } else {
             enter_levels(in, out, n, count, s, scratch_, 1, ln);
         }
@@ -1386,9 +1388,17 @@ public:
     // to shorten a sweep is to spread a tile's pairs over more CUs.  For 32-byte fields launches with < kSmallTiles tiles of
     // the default size use 4x smaller tiles: 256 elements, 128-thread low-level kernels, one wave per SIMD.
     static constexpr unsigned kLogLowSmall = 8, kBlockLowSmall = 128, kSmallTiles = 256;
-    static unsigned small_tiles_max() { static const unsigned v = getenv("ECFFT_SMALL_TILES_MAX") ? (unsigned)atoi(getenv("ECFFT_SMALL_TILES_MAX")) : kSmallTiles; return v; }   // A/B knob
-    static bool small_launch(size_t total) { return sizeof(E) == 32 && (total >> kLogLow) < small_tiles_max() && total >= ((size_t)1 << kLogLowSmall); }
-    unsigned log_low_for(size_t total) const { return small_launch(total) && !ef_small_off_ ? kLogLowSmall : kLogLow; }
+    // Round 4: the fused PASSES (row / column kernels) of a launch on ONE stream switch to the small tiles below 2 x kSmallTiles tiles
+    // (a 2^18 launch is 256 big tiles = half the workgroup slots: ENTER at 2^18 0.77 -> 0.69 ms); inside the two-halves schedule the
+    // other stream fills the chip and the rule stays at kSmallTiles (2^20 with 512: +14 %).  The low-level kernels keep kSmallTiles.
+    // ECFFT_SMALL_TILES_MAX / ECFFT_SMALL_LOW_MAX: A/B knobs for both.
+    unsigned small_tiles_max() const {
+        static const int v = getenv("ECFFT_SMALL_TILES_MAX") ? atoi(getenv("ECFFT_SMALL_TILES_MAX")) : -1;
+        return v >= 0 ? (unsigned)v : (in_halves_ ? kSmallTiles : 2 * kSmallTiles);
+    }
+    bool small_launch(size_t total) const { return sizeof(E) == 32 && (total >> kLogLow) < small_tiles_max() && total >= ((size_t)1 << kLogLowSmall); }
+    static unsigned small_low_max() { static const unsigned v = getenv("ECFFT_SMALL_LOW_MAX") ? (unsigned)atoi(getenv("ECFFT_SMALL_LOW_MAX")) : kSmallTiles; return v; }
+    unsigned log_low_for(size_t total) const { return sizeof(E) == 32 && (total >> kLogLow) < small_low_max() && total >= ((size_t)1 << kLogLowSmall) && !ef_small_off_ ? kLogLowSmall : kLogLow; }
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
     bool exit(const E* in, E* out, size_t n1, size_t count, hipStream_t s) {
@@ -1398,7 +1408,9 @@ public:
         unsigned ln = ilog2(n1);
         if (count == 1 && ln >= kSplitMinLog && nside_ > 0) {
             int next_side = 0;
+            in_halves_ = true;
             exit_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
+            in_halves_ = false;
         } else {
             exit_levels(in, out, n1, count, s, scratch_, ln, 1);
         }
@@ -2083,6 +2095,7 @@ private:
     bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
     bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
     unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
+    bool in_halves_ = false;                                            // enqueueing the two-halves schedule of one transform (caller holds lock())
     Tree pair_full_{}; bool have_pair_full_ = false;                    // EXIT-shard contexts: the full tree T_2c (c = n / world) of the redundant pair level
     // full contexts: split EXITs of at most 2^this run every top level redundantly after one all-gather (0: never) — api_exit_split
     unsigned gather_max_log_ = getenv("ECFFT_SPLIT_GATHER_MAX_LOG") ? (unsigned)atoi(getenv("ECFFT_SPLIT_GATHER_MAX_LOG")) : 21u;
