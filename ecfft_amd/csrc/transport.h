@@ -133,7 +133,9 @@ public:
         RcclApi& api = RcclApi::get();
         if (!comm_ || !api.CommAbort) return false;
         aborted_ = true;
-        return api.CommAbort(comm_) == 0;
+        RcclApi::Comm c = comm_;
+        comm_ = nullptr;                                  // ncclCommAbort also frees the communicator: no ncclCommDestroy afterwards
+        return api.CommAbort(c) == 0;
     }
     bool init(const void* id128, int world_, int rank_, int device_) {
         RcclApi& api = RcclApi::get();
@@ -147,7 +149,7 @@ public:
 protected:
     bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
         RcclApi& api = RcclApi::get();
-        if (aborted_) return false;
+        if (aborted_ || !comm_) return false;
         const int kChar = 0;                              // ncclChar / ncclInt8
         int rc = api.GroupStart();
         for (int i = 0; i < ns && rc == 0; ++i) rc = api.Send(sends[i].ptr, sends[i].bytes, kChar, sends[i].peer, comm_, s);

@@ -132,9 +132,11 @@ int ncclCommDestroy(void* comm) {
     delete c;
     return 0;
 }
-int ncclCommAbort(void* comm) {
-    Comm* c = (Comm*)comm;
-    if (c) c->ctl->aborted.store(1);
+int ncclCommAbort(void* comm) {          // like the real one it also retires the communicator (no ncclCommDestroy afterwards); the
+    Comm* c = (Comm*)comm;               // mapping stays: another thread of the caller may still sit in do_recv on it
+    if (!c) return 0;
+    c->ctl->aborted.store(1);
+    if (c->ctl->detached.fetch_add(1) + 1 == (uint32_t)c->nranks) shm_unlink(("/" + c->token + "_ctl").c_str());
     return 0;
 }
 int ncclGroupStart() { ++g_depth; return 0; }
