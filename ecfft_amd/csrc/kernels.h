@@ -783,7 +783,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
 }
 
 // forward declaration (defined with the low-level kernels below)
-template <class F, int BLK>
+template <class F, int BLK, bool SWZ = false>
 __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
                                              const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
@@ -1255,6 +1255,33 @@ struct LevelTables {
 #ifndef ECFFT_REG_ENGINE
 #define ECFFT_REG_ENGINE 1
 #endif
+#ifndef ECFFT_LDS_SWZ
+#define ECFFT_LDS_SWZ 1      // k_exit_low<10,512>: XOR-swizzled LDS layout of the 32-byte elements (A/B: -DECFFT_LDS_SWZ=0)
+#endif
+// LDS layout of an array of 32-byte elements that ds_read_b128 / ds_write_b128 reach without bank conflicts (round 4): the 16-byte
+// chunks 2j, 2j + 1 of element j are XOR-ed with (j >> 3) & 3 inside their 256-byte row (16 chunks = all 64 banks).  A wave-wide
+// access takes the same half of each element: in the plain layout the 16 lanes of one of ds_read_b128's groups hit every second bank
+// quad twice for consecutive elements (2-way: the 2.1x of SQ_LDS_BANK_CONFLICT over active LDS cycles in k_exit_low) and every fourth
+// one four times for the stride-2 de-interleaving reads; with the XOR both patterns cover all sixteen quads.
+template <class F, bool SWZ>
+__device__ __forceinline__ typename F::elem lds_get(const typename F::elem* a, uint32_t j) {
+    if constexpr (SWZ && sizeof(typename F::elem) == 32) {
+        const uint4* p = reinterpret_cast<const uint4*>(a);
+        const uint32_t sx = (j >> 3) & 3u;
+        const uint4 lo = p[(2 * j) ^ sx], hi = p[(2 * j + 1) ^ sx];
+        typename F::elem r; r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w; r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+        return r;
+    } else return a[j];
+}
+template <class F, bool SWZ>
+__device__ __forceinline__ void lds_put(typename F::elem* a, uint32_t j, const typename F::elem& x) {
+    if constexpr (SWZ && sizeof(typename F::elem) == 32) {
+        uint4* p = reinterpret_cast<uint4*>(a);
+        const uint32_t sx = (j >> 3) & 3u;
+        p[(2 * j) ^ sx] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        p[(2 * j + 1) ^ sx] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    } else a[j] = x;
+}
 template <class F>
 __device__ __forceinline__ typename F::elem lane_xor(const typename F::elem& x, uint32_t h) {
     typename F::elem r;
@@ -1366,7 +1393,7 @@ __global__ __launch_bounds__(512, 2) void k_stages_col_enter256(const typename F
     }
 }
 
-template <class F, int BLK>
+template <class F, int BLK, bool SWZ>
 __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, uint32_t log_e, uint32_t k_first,
                                              const typename F::telem* __restrict__ c0t, const typename F::telem* __restrict__ dinv,
                                              const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
@@ -1378,13 +1405,14 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
     static_assert(sizeof(E) == 32, "32-byte fields");
     const bool act = tid < len;                                             // len is a multiple of 64: wave-uniform
     const size_t e = (size_t)1 << log_e;
-    E x = act ? a[tid] : F::zero();
+    // SWZ: `a` is read and written in the XOR-swizzled layout (lds_get / lds_put); the matrix-core phase uses its own operand layout
+    E x = act ? lds_get<F, SWZ>(a, tid) : F::zero();
     auto partner = [&](uint32_t h) -> E {
         if (h < 64) return act ? lane_xor<F>(x, h) : x;
         __syncthreads();                                                    // readers of the previous LDS exchange are done
-        if (act) a[tid] = x;
+        if (act) lds_put<F, SWZ>(a, tid, x);
         __syncthreads();
-        return act ? a[tid ^ h] : x;
+        return act ? lds_get<F, SWZ>(a, tid ^ h) : x;
     };
     const uint32_t k_inner = log_e ? log_e - 1 : 0;
     bool mfma = false;
@@ -1428,13 +1456,13 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
         }
     }
     __syncthreads();
-    if (act) a[tid] = x;
+    if (act) lds_put<F, SWZ>(a, tid, x);
     __syncthreads();
 }
 
 // every stage (decompose then recombine) of EXTEND on `len` LDS elements = len/e vectors of length e;
 // srcpar = parity of the source moiety.  Ends with a barrier.
-template <class F, int BLK = kBlockLds>
+template <class F, int BLK = kBlockLds, bool SWZ = false>      // SWZ: `a` in the XOR-swizzled layout — only the register engine (len <= BLK) reads it that way
 __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<F>& T, int srcpar) {
     using E = typename F::elem;
     const uint32_t tid = threadIdx.x, npairs = len >> 1;
@@ -1451,10 +1479,11 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     }
     if constexpr (sizeof(E) == 32 && ECFFT_REG_ENGINE) {
         if (len <= (uint32_t)BLK && (len & 63u) == 0) {
-            reg_extend32<F, BLK>(a, len, log_e, 0, T.c0t[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], tid, len == (uint32_t)BLK ? bA : nullptr, bK);
+            reg_extend32<F, BLK, SWZ>(a, len, log_e, 0, T.c0t[srcpar], T.dinv[srcpar], T.p0[tgt], T.p1[tgt], T.inner[srcpar], tid, len == (uint32_t)BLK ? bA : nullptr, bK);
             return;
         }
     }
+    if constexpr (SWZ) __builtin_trap();      // unreachable: the callers that swizzle pass len == BLK
     if constexpr (sizeof(E) == 32) {
         if (len == BLK) {
             // PAIR-SPLIT sweeps (k_exit_low: half as many pairs as threads).  One butterfly = two multiplies; with one pair per
@@ -1711,6 +1740,9 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
     E* H = G + nh;
     const size_t base = (size_t)blockIdx.x << log_tile;
     constexpr bool kQuad = sizeof(E) == 4 && nh % (4 * BLK) == 0;
+    // cur / G / H in the XOR-swizzled layout (lds_get / lds_put: no bank conflicts for consecutive elements) — the 1024-element
+    // variant of 32-byte fields, whose EXTEND cores run on the register engine
+    constexpr bool kSwz = ECFFT_LDS_SWZ && sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512;
     bool qio = false;                                                      // user pointers may be only element-aligned
     if constexpr (kQuad) qio = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     if constexpr (kQuad) {
@@ -1724,9 +1756,10 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
         }
     }
     if (!qio) {
-        for (uint32_t j = tid; j < T; j += BLK) cur[j] = src[base + j];
+        for (uint32_t j = tid; j < T; j += BLK) lds_put<F, kSwz>(cur, j, src[base + j]);
     }
     __syncthreads();
+    bool cur_swz = kSwz;                                                    // the final matrix-core phase leaves `cur` in the plain layout
     uint32_t l_last = 1;
     const uint8_t* lA = nullptr;
     const uint8_t* lA32 = nullptr;
@@ -1815,52 +1848,60 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
                 continue;
             }
         }
-        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(ldt(L.A1, g & (e - 1)), cur[2 * g]);
+        for (uint32_t g = tid; g < nh; g += BLK) lds_put<F, kSwz>(G, g, F::tmul(ldt(L.A1, g & (e - 1)), lds_get<F, kSwz>(cur, 2 * g)));
         __syncthreads();
-        lds_extend_core<F, BLK>(G, nh, le, L, 0);
+        lds_extend_core<F, BLK, kSwz>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
-            E r = F::tmul_add(ldt(L.NB2, i), G[g], F::tmul(ldt(L.B1, i), cur[2 * g + 1]));
-            G[g] = r; H[g] = r;
+            E r = F::tmul_add(ldt(L.NB2, i), lds_get<F, kSwz>(G, g), F::tmul(ldt(L.B1, i), lds_get<F, kSwz>(cur, 2 * g + 1)));
+            lds_put<F, kSwz>(G, g, r); lds_put<F, kSwz>(H, g, r);
         }
         __syncthreads();
-        lds_extend_core<F, BLK>(G, nh, le, L, 1);
-        for (uint32_t g = tid; g < nh; g += BLK) G[g] = F::tmul(ldt(L.C1, g & (e - 1)), G[g]);
+        lds_extend_core<F, BLK, kSwz>(G, nh, le, L, 1);
+        for (uint32_t g = tid; g < nh; g += BLK) lds_put<F, kSwz>(G, g, F::tmul(ldt(L.C1, g & (e - 1)), lds_get<F, kSwz>(G, g)));
         __syncthreads();
-        lds_extend_core<F, BLK>(G, nh, le, L, 0);
+        lds_extend_core<F, BLK, kSwz>(G, nh, le, L, 0);
         for (uint32_t g = tid; g < nh; g += BLK) {
             uint32_t i = g & (e - 1);
-            G[g] = F::tmul_add(ldt(L.NB2, i), G[g], F::tmul(ldt(L.D1, i), H[g]));
+            lds_put<F, kSwz>(G, g, F::tmul_add(ldt(L.NB2, i), lds_get<F, kSwz>(G, g), F::tmul(ldt(L.D1, i), lds_get<F, kSwz>(H, g))));
         }
         __syncthreads();
-        lds_extend_core<F, BLK>(G, nh, le, L, 1);
+        lds_extend_core<F, BLK, kSwz>(G, nh, le, L, 1);
         E u[PAIRS], v[PAIRS];
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1);
-            u[c] = F::tmul(ldt(L.w[0], i), G[g]);
-            v[c] = F::tmul(ldt(L.xie, i), F::sub(cur[2 * g], u[c]));
+            u[c] = F::tmul(ldt(L.w[0], i), lds_get<F, kSwz>(G, g));
+            v[c] = F::tmul(ldt(L.xie, i), F::sub(lds_get<F, kSwz>(cur, 2 * g), u[c]));
         }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < PAIRS; ++c) {
             uint32_t g = tid + (uint32_t)c * BLK, i = g & (e - 1), bb = (g >> le) << l;
-            cur[bb + i] = u[c]; cur[bb + e + i] = v[c];
+            lds_put<F, kSwz>(cur, bb + i, u[c]); lds_put<F, kSwz>(cur, bb + e + i, v[c]);
         }
         __syncthreads();
     }
     if constexpr (sizeof(E) == 32 && LOG_TILE == 10 && BLK == 512) {
         if (lA32) {             // levels 5..1 on the matrix cores: one 32 x 32 map per 32-block
+            if constexpr (kSwz) {                                          // (off by default: the plain layout first)
+                const E x0 = lds_get<F, true>(cur, tid), x1 = lds_get<F, true>(cur, tid + 512);
+                __syncthreads();
+                cur[tid] = x0; cur[tid + 512] = x1;
+                __syncthreads();
+            }
             Blk16::to_operand_form32(cur, tid);
             Blk16::phase32(cur, lA32, trees[5].low32_K[1], tid);
             Blk16::from_swizzled32(cur, tid);
+            cur_swz = false;
         } else
         if (lA) {               // levels 4..1 on the matrix cores: one 16 x 16 map per 16-block
             Blk16::APre pre = Blk16::prefetch(lA, tid);
             __builtin_amdgcn_sched_barrier(0);
-            Blk16::to_operand_form<BLK>(cur, T, tid);
+            Blk16::to_operand_form<BLK, kSwz>(cur, T, tid);
             Blk16::phase(cur, lA, trees[4].low16_K[1], tid, pre);
             Blk16::from_swizzled<BLK>(cur, T, tid);
+            cur_swz = false;
         }
     }
     if constexpr (sizeof(E) == 32 && LOG_TILE == 8 && BLK == 128) {
@@ -1882,7 +1923,8 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
             return;
         }
     }
-    for (uint32_t j = tid; j < T; j += BLK) dst[base + j] = F::canon(cur[j]);
+    if (cur_swz) { for (uint32_t j = tid; j < T; j += BLK) dst[base + j] = F::canon(lds_get<F, kSwz>(cur, j)); }
+    else for (uint32_t j = tid; j < T; j += BLK) dst[base + j] = F::canon(cur[j]);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -129,15 +129,17 @@ struct Blk16 {
     }
 
     // plain tile (T elements, T a multiple of 512) -> operand form: bytes xor 0x80, chunks swizzled.  Ends with a barrier.
-    template <int BLK>
+    // SWZ: the tile comes in the XOR-swizzled layout of kernels.h (lds_get / lds_put) instead of the plain one
+    template <int BLK, bool SWZ = false>
     __device__ static __forceinline__ void to_operand_form(E* tile, uint32_t T, uint32_t tid) {
         uint4* lds = reinterpret_cast<uint4*>(tile);
 #pragma unroll 1
         for (uint32_t base = 0; base < T; base += 2 * BLK) {       // 2 elements per thread per round
             const uint32_t j0 = base + tid, j1 = base + BLK + tid;
             const bool two = j1 < T;
-            uint4 a0 = lds[2 * j0], a1 = lds[2 * j0 + 1], b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-            if (two) { b0 = lds[2 * j1]; b1 = lds[2 * j1 + 1]; }
+            const uint32_t s0 = SWZ ? ((j0 >> 3) & 3u) : 0u, s1 = SWZ ? ((j1 >> 3) & 3u) : 0u;
+            uint4 a0 = lds[(2 * j0) ^ s0], a1 = lds[(2 * j0 + 1) ^ s0], b0 = make_uint4(0, 0, 0, 0), b1 = b0;
+            if (two) { b0 = lds[(2 * j1) ^ s1]; b1 = lds[(2 * j1 + 1) ^ s1]; }
             __syncthreads();
             const uint32_t X = 0x80808080u;
             lds[phys(j0, 0)] = make_uint4(a0.x ^ X, a0.y ^ X, a0.z ^ X, a0.w ^ X);
