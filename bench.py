@@ -280,6 +280,30 @@ def main():
                    "field_mul_per_s_per_gpu": (we_ + wx_) * B * args.steps / tb}
         del big, evb, backb
 
+    # ---- extra: the latency regime (BASELINE.json configs[1], n = 2^16, and 2^17 = the rank-local chunk of an 8-GPU split at 2^20):
+    # one transform, device buffers, median of 15 — reported beside the headline, never part of `value` ----
+    latency = None
+    if world == 1 and args.field == "secp256k1" and args.log_n == 20 and args.steps > 0 and not os.environ.get("ECFFT_BENCH_NO_LATENCY"):
+        latency = {}
+        for ln in (16, 17):
+            ts = F.build_fftree(1 << ln, device=local_rank)
+            hs = synth(args.field, 1 << ln, 0x5EED0000 + ln)
+            xs = torch.from_numpy(hs.view(np.int64)).cuda()
+            for _ in range(3):
+                ys = ts.exit(ts.enter(xs))
+            assert torch.equal(ys, xs), "EXIT(ENTER(c)) != c in the latency regime"
+            tl = []
+            for _ in range(15):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ys = ts.exit(ts.enter(xs))
+                torch.cuda.synchronize(); tl.append(time.perf_counter() - t0)
+            wl = sum(w_mul(1 << ln))
+            med = sorted(tl)[len(tl) // 2]
+            latency[f"2^{ln}"] = {"enter_exit_ms": med * 1e3, "field_mul_per_s": wl / med}
+            del ts, xs, ys
+        latency["note"] = ("ONE ENTER+EXIT per size (median of 15, device buffers, round trip asserted): launches with fewer tiles than CUs run the "
+                           "256-element register / 16x16x64 matrix-core kernels (DESIGN.md 5.1); 2^16 is BASELINE.json configs[1]")
+
     out = None
     if rank == 0:
         we, wx = w_mul(n)
@@ -299,6 +323,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": None,
             "batched": batched,
+            "latency_regime": latency,
         }
         out.update(split)
 
