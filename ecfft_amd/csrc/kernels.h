@@ -1255,6 +1255,9 @@ struct LevelTables {
 #ifndef ECFFT_REG_ENGINE
 #define ECFFT_REG_ENGINE 1
 #endif
+#ifndef ECFFT_N16_DEPTH2W
+#define ECFFT_N16_DEPTH2W 2     // units of constant matrices in flight in the two-wave 16x16x64 phases of k_exit_low<8,128> (1: 252 instead of 284 VGPRs, measured 0.6-1.2 % slower)
+#endif
 #ifndef ECFFT_LDS_SWZ
 #define ECFFT_LDS_SWZ 1      // k_exit_low<10,512>: XOR-swizzled LDS layout of the 32-byte elements (A/B: -DECFFT_LDS_SWZ=0)
 #endif
@@ -1432,7 +1435,7 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
     if constexpr (BLK == 512 || BLK == 256 || BLK == 128) {
         if (mfma) {                                                         // len == BLK: every thread holds an element
             if constexpr (BLK == 512) x = Blk16::phase512_regs(a, x, blkA, blkK, tid);
-            else x = Blk16::phase_n16_regs<BLK / 64>(a, x, blkA, blkK, tid);   // small launches: v_mfma_i32_16x16x64_i8
+            else x = Blk16::phase_n16_regs<BLK / 64, (BLK == 128 ? ECFFT_N16_DEPTH2W : 2)>(a, x, blkA, blkK, tid);   // small launches: v_mfma_i32_16x16x64_i8
         }
     }
     if (log_e > 0 && k_first <= k_inner && !mfma) {                         // merged innermost stage pair (h = 1)
@@ -1906,7 +1909,7 @@ __global__ __launch_bounds__(BLK, (BLK >= 512 ? ECFFT_MIN_WAVES : 1)) void k_exi
     }
     if constexpr (sizeof(E) == 32 && LOG_TILE == 8 && BLK == 128) {
         if (lA) {               // latency variant: 16 blocks on two waves (v_mfma_i32_16x16x64_i8), two results per lane
-            Blk16::phase_n16<2, false>(cur, lA, trees[4].low16_K[1], tid, [&] { Blk16::to_operand_form<BLK>(cur, T, tid); });
+            Blk16::phase_n16<2, false, ECFFT_N16_DEPTH2W>(cur, lA, trees[4].low16_K[1], tid, [&] { Blk16::to_operand_form<BLK>(cur, T, tid); });
             Blk16::from_swizzled<BLK>(cur, T, tid);
         }
     }
