@@ -573,8 +573,8 @@ N_SIMD = 256 * 4
 
 
 # environment switches that change which kernels / code paths run (A/B tools): the committed PMC counters do not apply then
-AB_SWITCHES = ("ECFFT_NO_MFMA", "ECFFT_NO_LOW16", "ECFFT_NO_FULL_CYCLIC", "ECFFT_NO_SMALL_TILES", "ECFFT_NO_ROW256", "ECFFT_NO_COL256",
-               "ECFFT_SMALL_MIN_LOGC", "ECFFT_LIB")
+AB_SWITCHES = ("ECFFT_NO_MFMA", "ECFFT_NO_LOW16", "ECFFT_LOW32", "ECFFT_NO_FULL_CYCLIC", "ECFFT_NO_SMALL_TILES", "ECFFT_NO_ROW256", "ECFFT_NO_COL256",
+               "ECFFT_SMALL_MIN_LOGC", "ECFFT_SMALL_TILES_MAX", "ECFFT_SMALL_LOW_MAX", "ECFFT_LIB")
 
 
 def _counters(field, log_n):
