@@ -190,6 +190,15 @@ __global__ void k_spin_us(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
+// every piece of one exchange in ONE launch, as RCCL moves a group (a launch per piece would bill the rank ~4 us of launch boundary per
+// peer and exchange that no real transport pays)
+struct ProjPieces { static constexpr int kMax = 64; void* dst[kMax]; const void* src[kMax]; unsigned long long n16[kMax]; int n; };
+__global__ void k_proj_copy(ProjPieces pc) {
+    const int piece = blockIdx.y;
+    if (piece >= pc.n) return;
+    const uint4* s = reinterpret_cast<const uint4*>(pc.src[piece]); uint4* d = reinterpret_cast<uint4*>(pc.dst[piece]);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < pc.n16[piece]; i += (unsigned long long)gridDim.x * blockDim.x) d[i] = s[i];
+}
 class ProjectionTransport : public Transport {
 public:
     ProjectionTransport(int world_, int rank_, int device_, double delay_us, double gbps) : delay_us_(delay_us), gbps_(gbps) { world = world_; rank = rank_; device = device_; }
@@ -202,12 +211,21 @@ protected:
         for (int i = 0; i < ns; ++i) remote = remote || sends[i].peer != rank;
         if (!remote) us = 0.0;                                                 // self send / receive only: no link involved
         if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, s, (unsigned long long)(us * 100.0));
+        ProjPieces pc; pc.n = 0; size_t most = 0;
         for (int i = 0; i < nr; ++i) {                                         // i-th receive <- i-th send (sizes agree for the group exchanges of the split transforms)
             const P2P& src = sends[i < ns ? i : ns - 1];
             const size_t b = recvs[i].bytes < src.bytes ? recvs[i].bytes : src.bytes;
-            if (b && recvs[i].ptr != src.ptr && hipMemcpyAsync(recvs[i].ptr, src.ptr, b, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+            if (!b || recvs[i].ptr == src.ptr) continue;
+            const bool vec = pc.n < ProjPieces::kMax && b % 16 == 0 && (reinterpret_cast<uintptr_t>(recvs[i].ptr) | reinterpret_cast<uintptr_t>(src.ptr)) % 16 == 0;
+            if (!vec) { if (hipMemcpyAsync(recvs[i].ptr, src.ptr, b, hipMemcpyDeviceToDevice, s) != hipSuccess) return false; continue; }
+            pc.dst[pc.n] = recvs[i].ptr; pc.src[pc.n] = src.ptr; pc.n16[pc.n] = b / 16; ++pc.n;
+            if (b / 16 > most) most = b / 16;
         }
-        return true;
+        if (pc.n) {
+            size_t bx = (most + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+            hipLaunchKernelGGL(k_proj_copy, dim3((unsigned)bx, (unsigned)pc.n), dim3(256), 0, s, pc);
+        }
+        return hipGetLastError() == hipSuccess;
     }
 private:
     double delay_us_, gbps_;
