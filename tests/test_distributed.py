@@ -546,3 +546,42 @@ def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(mon
     assert FT.lib().ecfft_test_fail_build_rank(-1) == 0
     _thread_ranks(2, lambda rank, make_comm: res.__setitem__(rank, F.build_exit_shard(1 << 12, make_comm()) is not None))
     assert res == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_projection_transport_bills_the_modelled_time_per_remote_exchange():
+    """ecfft_comm_init_projection (measurement only, tools/split_project.py): rank 0 of a 4-rank job on its own.  The exchange count and
+    the bytes are those of the real split ENTER; an injected delay shows up on the stream once per exchange with a remote peer; the
+    self pieces move (the output is this rank's data pushed through the launches, of the right size — its values mean nothing)."""
+    import time
+    import torch
+    import ecfft_amd
+    from ecfft_amd import distributed as D
+    F = ecfft_amd.FIELDS["secp256k1"]
+    n, P = 1 << 14, 4
+    c = n // P
+    shard = F.build_enter_shard(n, P, 0)
+    a = np.random.default_rng(8).integers(0, 2**64, size=(c, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+    mine = torch.from_numpy(a.view(np.int64)).cuda()
+
+    def timed(delay_us):
+        comm = D.Comm.projection(P, 0, 0, delay_us, 0.0)
+        out = shard.enter_sharded(comm, mine, n)
+        assert out.shape == mine.shape
+        comm.stats(True)
+        shard.enter_sharded(comm, mine, n)
+        torch.cuda.synchronize()
+        st = comm.stats()
+        comm.stats(False)
+        ts = []
+        for _ in range(7):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            shard.enter_sharded(comm, mine, n)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], st
+
+    t_zero, st0 = timed(0.0)
+    t_slow, st1 = timed(400.0)
+    assert st0["exchanges"] == st1["exchanges"] == 5 and st0["bytes_sent"] == st1["bytes_sent"] > 0      # 2 levels x 2 + the final re-blocking
+    exposed = t_slow - t_zero
+    assert 0.6 * 5 * 400e-6 < exposed < 1.6 * 5 * 400e-6, (t_zero, t_slow)
