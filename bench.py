@@ -150,8 +150,8 @@ def _cpu_name():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--field", default="secp256k1", choices=["secp256k1", "m31"])
     ap.add_argument("--cpu-log-n", type=int, default=15, help="size of the bounded CPU-baseline sample (0 = skip)")
@@ -199,6 +199,10 @@ def main():
 
     n = 1 << args.log_n
     F = ecfft_amd.FIELDS[args.field]
+    # host-side input first, so that nothing but the upload separates the device's first work (context, tree build) from the warm-up steps:
+    # an idle gap of tens of ms lets the chip drop its clocks, and the first 3 - 4 steps after one run 5 - 30 % slow (tools/ramp_check.py)
+    host = synth(args.field, n, 0x5EED0000 + 2 + rank)
+    view = host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)
     # the process's first device work (HIP context, queues, module load: 0.1 - 0.2 s on this stack) is not tree construction:
     # it is timed on its own so that tree_build_s is what ecfft_build_fftree costs a process that already uses its GPU
     t_init0 = time.perf_counter()
@@ -211,8 +215,6 @@ def main():
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t_build0
 
-    host = synth(args.field, n, 0x5EED0000 + 2 + rank)
-    view = host.view(np.int64) if args.field == "secp256k1" else host.view(np.int32)
     coeffs = torch.from_numpy(view).cuda()          # resident in HBM before the timed region
 
     def barrier():
