@@ -211,6 +211,7 @@ protected:
         for (int i = 0; i < ns; ++i) remote = remote || sends[i].peer != rank;
         if (!remote) us = 0.0;                                                 // self send / receive only: no link involved
         if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, s, (unsigned long long)(us * 100.0));
+        if (ns <= 0) return nr == 0;                                           // nothing of this rank's to stand in for a peer's data
         ProjPieces pc; pc.n = 0; size_t most = 0;
         for (int i = 0; i < nr; ++i) {                                         // i-th receive <- i-th send (sizes agree for the group exchanges of the split transforms)
             const P2P& src = sends[i < ns ? i : ns - 1];
