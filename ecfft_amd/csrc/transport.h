@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -128,13 +129,15 @@ private:
 
 class RcclTransport : public Transport {
 public:
-    ~RcclTransport() override { if (comm_) (void)RcclApi::get().CommDestroy(comm_); }
+    ~RcclTransport() override { if (RcclApi::Comm c = comm_.load()) (void)RcclApi::get().CommDestroy(c); }
+    // may be called from another thread than the one blocked in an exchange (that is its purpose): the handle is swapped out atomically,
+    // so exactly one caller aborts it and an exchange that starts afterwards sees no communicator
     bool abort() override {
         RcclApi& api = RcclApi::get();
-        if (!comm_ || !api.CommAbort) return false;
-        aborted_ = true;
-        RcclApi::Comm c = comm_;
-        comm_ = nullptr;                                  // ncclCommAbort also frees the communicator: no ncclCommDestroy afterwards
+        if (!api.CommAbort) return false;
+        aborted_.store(true);
+        RcclApi::Comm c = comm_.exchange(nullptr);        // ncclCommAbort also frees the communicator: no ncclCommDestroy afterwards
+        if (!c) return false;
         return api.CommAbort(c) == 0;
     }
     bool init(const void* id128, int world_, int rank_, int device_) {
@@ -142,26 +145,29 @@ public:
         if (!api.ok()) return false;
         RcclApi::UniqueId id; memcpy(id.internal, id128, sizeof(id.internal));
         world = world_; rank = rank_; device = device_;
-        int rc = api.CommInitRank(&comm_, world, id, rank);
-        if (rc != 0) { fprintf(stderr, "ecfft: ncclCommInitRank failed: %s\n", api.GetErrorString ? api.GetErrorString(rc) : "?"); comm_ = nullptr; return false; }
+        RcclApi::Comm c = nullptr;
+        int rc = api.CommInitRank(&c, world, id, rank);
+        if (rc != 0) { fprintf(stderr, "ecfft: ncclCommInitRank failed: %s\n", api.GetErrorString ? api.GetErrorString(rc) : "?"); return false; }
+        comm_.store(c);
         return true;
     }
 protected:
     bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
         RcclApi& api = RcclApi::get();
-        if (aborted_ || !comm_) return false;
+        RcclApi::Comm c = comm_.load();
+        if (aborted_.load() || !c) return false;
         const int kChar = 0;                              // ncclChar / ncclInt8
         int rc = api.GroupStart();
-        for (int i = 0; i < ns && rc == 0; ++i) rc = api.Send(sends[i].ptr, sends[i].bytes, kChar, sends[i].peer, comm_, s);
-        for (int i = 0; i < nr && rc == 0; ++i) rc = api.Recv(recvs[i].ptr, recvs[i].bytes, kChar, recvs[i].peer, comm_, s);
+        for (int i = 0; i < ns && rc == 0; ++i) rc = api.Send(sends[i].ptr, sends[i].bytes, kChar, sends[i].peer, c, s);
+        for (int i = 0; i < nr && rc == 0; ++i) rc = api.Recv(recvs[i].ptr, recvs[i].bytes, kChar, recvs[i].peer, c, s);
         int rc2 = api.GroupEnd();
         if (rc == 0) rc = rc2;
         if (rc != 0) fprintf(stderr, "ecfft: RCCL exchange failed: %s\n", api.GetErrorString ? api.GetErrorString(rc) : "?");
         return rc == 0;
     }
 private:
-    RcclApi::Comm comm_ = nullptr;
-    bool aborted_ = false;
+    std::atomic<RcclApi::Comm> comm_{nullptr};
+    std::atomic<bool> aborted_{false};
 };
 
 class CallbackTransport : public Transport {
