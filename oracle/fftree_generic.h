@@ -524,6 +524,18 @@ static void ec_leaves(const wcurve* c, ecpoint offset, ecpoint gen, fe* leaves, 
     for (size_t i = 0; i < n; ++i) { leaves[i] = ec_add(c, offset, acc).x; acc = ec_add(c, acc, gen); }
 }
 
+/* individual leaves x(coset_offset + idx*G) of the same point set (src/lib.rs:72-78, src/ec.rs:545-551) without walking the whole
+ * coset: idx*G by double-and-add on the reference's affine group law.  Test infrastructure: gives the spot checks at sizes whose
+ * oracle tree would take minutes (n >= 2^22) leaves that do not come from the library under test. */
+static void ec_leaves_at(const wcurve* c, ecpoint offset, ecpoint gen, const uint64_t* idx, size_t k, fe* out) {
+    for (size_t j = 0; j < k; ++j) {
+        ecpoint acc; acc.inf = 1; acc.x = acc.y = fe_zero();
+        ecpoint dbl = gen;
+        for (uint64_t e = idx[j]; e; e >>= 1) { if (e & 1) acc = ec_add(c, acc, dbl); dbl = ec_add(c, dbl, dbl); }
+        out[j] = ec_add(c, offset, acc).x;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * exported C interface (loaded by tests/ and bench.py through ctypes)
  * ---------------------------------------------------------------------------------------- */

@@ -49,6 +49,7 @@ class _Field:
         self._sig("inv_vec", None, [ctypes.c_void_p] * 2 + [ctypes.c_size_t])
         for f in ("from_std", "to_std"):
             self._sig(f, None, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t])
+        self._sig("leaves_at", ctypes.c_int, [ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
 
     def _sig(self, name, res, args):
         fn = getattr(self.lib, f"{self.prefix}{name}")
@@ -112,6 +113,15 @@ class _Field:
         a, pa = self._c(a)
         out = np.zeros_like(a)
         self._inv_vec(pa, out.ctypes.data_as(ctypes.c_void_p), self.count(a))
+        return out
+
+    def leaves_at(self, n, idx):
+        """leaves idx of the n-leaf point set `build_fftree(n)` would use, x(coset_offset + i*G) (src/lib.rs:72-78), computed
+        one by one by double-and-add — independent of any tree, for spot checks at sizes whose oracle tree takes minutes"""
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = self.empty(len(idx))
+        rc = self._leaves_at(n.bit_length() - 1, idx.ctypes.data_as(ctypes.c_void_p), len(idx), out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
         return out
 
     def horner(self, coeffs, xs):

@@ -148,5 +148,16 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
     free(maps); fe_free(leaves);
     return t;
 }
+/* leaves idx[0..k) of the n = 2^log_n point set of build_fftree above (src/lib.rs:201-206, src/ec.rs:518-521, 545-551) */
+int ORA(leaves_at)(unsigned log_n, const uint64_t* idx, size_t k, void* out) {
+    swcurve curve = {1, 0};
+    ecpoint offset = {1048755163u, 279503108u, 0}, gen = {1273083559u, 804329170u, 0};
+    const unsigned two_adicity = 28;
+    if (log_n > two_adicity) return -1;
+    wcurve w = swcurve_w(&curve);
+    for (unsigned i = 0; i < two_adicity - log_n; ++i) gen = ec_add(&w, gen, gen);
+    ec_leaves_at(&w, offset, gen, idx, k, (fe*)out);
+    return 0;
+}
 void ORA(from_std)(const void* in, void* out, size_t n) { memcpy(out, in, n * sizeof(fe)); }
 void ORA(to_std)(const void* in, void* out, size_t n) { memcpy(out, in, n * sizeof(fe)); }

@@ -90,6 +90,25 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
     free(maps); fe_free(leaves);
     return t;
 }
+/* leaves idx[0..k) of the n = 2^log_n point set of build_fftree above (same constants, src/lib.rs:45-78); 0 on success */
+int ORA(leaves_at)(unsigned log_n, const uint64_t* idx, size_t k, void* out) {
+    goodcurve curve;
+    if (!goodcurve_new_odd(
+            fe_from_dec("31172306031375832341232376275243462303334845584808513005362718476441963632613"),
+            fe_from_dec("45508371059383884471556188660911097844526467659576498497548207627741160623272"), &curve))
+        return -1;
+    ecpoint offset, gen; offset.inf = gen.inf = 0;
+    offset.x = fe_from_dec("105623886150579165427389078198493427091405550492761682382732004625374789850161");
+    offset.y = fe_from_dec("7709812624542158994629670452026922591039826164720902911013234773380889499231");
+    gen.x = fe_from_dec("41293412487153066667050767300223451435019201659857889215769525847559135483332");
+    gen.y = fe_from_dec("73754924733368840065089190002333366411120578552679996887076912271884749237510");
+    const unsigned two_adicity = 36;
+    if (log_n >= two_adicity) return -1;
+    wcurve w = goodcurve_w(&curve);
+    for (unsigned i = 0; i < two_adicity - log_n; ++i) gen = ec_add(&w, gen, gen);
+    ec_leaves_at(&w, offset, gen, idx, k, (fe*)out);
+    return 0;
+}
 /* Montgomery <-> standard form (little-endian 32 bytes per element) */
 void ORA(from_std)(const void* in, void* out, size_t n) {
     for (size_t i = 0; i < n; ++i) ((fe*)out)[i] = fe_from_std(((const uint64_t*)in) + 4 * i);

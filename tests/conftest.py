@@ -48,3 +48,22 @@ def std_to_field(F, std):
     out = np.zeros_like(std)
     F._from_std(std.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), std.shape[0])
     return out
+
+
+def horner_mt(F, coeffs, xs, threads=None):
+    """F.horner (the oracle's naive evaluation, the expected side of the reference's tests, src/lib.rs:108-120) on many
+    points, the points split over host threads (the oracle is called through ctypes, which releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or max(1, min(16, (os.cpu_count() or 1)))
+    parts = [p for p in np.array_split(np.arange(len(xs)), threads) if len(p)]
+    with ThreadPoolExecutor(len(parts)) as ex:
+        outs = list(ex.map(lambda p: F.horner(coeffs, xs[p]), parts))
+    return np.concatenate(outs, axis=0)
+
+
+def spread_indices(n, count=1024, seed=0):
+    """`count` seeded positions in [0, n) that hit every residue mod `count` once (every position inside a `count`-element
+    tile) and both halves of the array (the two half-streams of a single large transform) about equally, plus the corners."""
+    rng = np.random.default_rng(seed)
+    idx = (np.arange(count) + count * rng.integers(0, max(1, n // count), count)) % n
+    return np.union1d(idx, np.array([0, 1, 2, n // 2 - 1, n // 2, n // 2 + 1, n - 2, n - 1]) % n)

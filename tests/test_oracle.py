@@ -18,6 +18,17 @@ def test_leaves_match_curve_constants(oracle_tree, field, n):
     assert np.array_equal(t.leaves(), std_to_field(F, g["leaves"]))
 
 
+@pytest.mark.parametrize("field", FIELDS)
+def test_leaves_at_equals_the_golden_leaves_and_the_subtree_rule(oracle_tree, oracle_mod, field):
+    """F.leaves_at (individual leaves by double-and-add, used by the GPU spot checks at sizes whose oracle tree would take
+    minutes) against the golden leaves, and the subtree relation leaves_n[i] = leaves_2n[2i] (src/fftree.rs:471-478)"""
+    F = oracle_mod.field(field)
+    g = load_golden(field, 4096)
+    idx = np.array([0, 1, 2, 3, 77, 2047, 2048, 4094, 4095])
+    assert np.array_equal(F.leaves_at(4096, idx), std_to_field(F, g["leaves"])[idx])
+    assert np.array_equal(F.leaves_at(1 << 22, 2 * idx), F.leaves_at(1 << 21, idx))
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_secp_rational_maps(oracle_tree, n):
     F, t = oracle_tree("secp256k1", n)
