@@ -30,6 +30,15 @@
 
 namespace ecfft {
 
+// A/B switches of the tuning experiments (ECFFT_NO_MFMA, ECFFT_NO_LOW16, ECFFT_LOW32, ECFFT_NO_ROW256, ...): a test / tuning build
+// (-DECFFT_TEST_HOOKS, tests/hooks/) reads them from the environment, the SHIPPED library has none of them — it reads no environment
+// variable at all, so two ranks of one job cannot end up on different exchange patterns because their environments differ.
+#ifdef ECFFT_TEST_HOOKS
+inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+inline const char* ab_env(const char*) { return nullptr; }
+#endif
+
 #define ECFFT_HIP_TRY(x)                                                                   \
     do { hipError_t e_ = (x); if (e_ != hipSuccess) {                                      \
              fprintf(stderr, "ecfft: HIP error '%s' at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -122,7 +131,9 @@ public:
     std::mutex& lock() { return mu_; }
     // test hook, process wide: the rank whose local part of the next collective ecfft_build_exit_shard reports failure (-1: none).
     // Set through the ABI only (ecfft_test_fail_build_rank) — no environment variable can reach it.
+#ifdef ECFFT_TEST_HOOKS
     static std::atomic<int>& test_fail_build_rank() { static std::atomic<int> r{-1}; return r; }
+#endif
     Profiler& profiler() const { return prof_; }
 
     // ------------------------------------------------------------------------------------------
@@ -597,7 +608,9 @@ public:
         };
         bool local_ok = local_part();
         fail_next_collective_ = false;
+#ifdef ECFFT_TEST_HOOKS
         if (test_fail_build_rank().load() == (int)rank) local_ok = false;   // test hook (ecfft_test_fail_build_rank): this rank's local part "fails"
+#endif
         if (!tr.vote(local_ok, s)) { fprintf(stderr, "ecfft: sharded EXIT build: the local part failed on %s rank\n", local_ok ? "another" : "this"); return false; }
         shard_kind_ = kShardExit; shard_log_p_ = log_p; shard_rank_ = rank;      // extend_split must read the shares from here on
         const E* f = fdev; const size_t N = N_;
@@ -1113,17 +1126,26 @@ public:
     bool collective_prepare(Transport& tr, int op, size_t len, int variant, hipStream_t s, Alloc alloc) {
         bool local_ok = true;
         try { alloc(); } catch (const DeviceAllocError&) { local_ok = false; }
-        if (fail_next_collective_) { local_ok = false; fail_next_collective_ = false; }        // test hook
         const uint64_t key = ((uint64_t)op << 60) | ((uint64_t)variant << 56) | ((uint64_t)(unsigned)tr.world << 48) | (uint64_t)len;
-        // an agreed shape cannot fail locally (its temporaries are pinned) — unless the test hook says so: then the ranks vote
-        // again, so that the peers that passed do not walk into the exchanges alone
-        if (agreed_shapes_.count(key) && local_ok) return true;
+        // An agreed shape cannot fail locally: its temporaries are pinned in the pool.  It therefore never votes again — a vote is a
+        // symmetric all-rank exchange, and a rank voting alone would pair its 4-byte messages with its peers' data messages
+        // (ADVICE r04).  Should the impossible happen, the rank reports the error and its peers are released by the caller's
+        // ecfft_comm_abort; the failure-injection hook only applies to shapes that still vote (it stays armed until one comes).
+        if (agreed_shapes_.count(key)) {
+            if (!local_ok) { fprintf(stderr, "ecfft: a pinned temporary of an agreed sharded call shape could not be taken\n"); temps_done(); }
+            return local_ok;
+        }
+#ifdef ECFFT_TEST_HOOKS
+        if (fail_next_collective_) { local_ok = false; fail_next_collective_ = false; }        // test hook
+#endif
         if (!tr.vote(local_ok, s)) { temps_done(); return false; }
         agreed_shapes_.insert(key);
         for (auto& b : pool_) if (b.busy) b.pinned = true;
         return true;
     }
+#ifdef ECFFT_TEST_HOOKS
     void test_fail_next_collective() { std::lock_guard<std::mutex> g(mu_); fail_next_collective_ = true; }
+#endif
     bool api_extend_split(Transport& tr, const E* in, E* out, size_t e, int target, hipStream_t s, bool cyc_in = false, bool cyc_out = false) {
         const size_t P = (size_t)tr.world, c = e / P;
         if (P & (P - 1)) return false;
@@ -1393,11 +1415,11 @@ public:
     // other stream fills the chip and the rule stays at kSmallTiles (2^20 with 512: +14 %).  The low-level kernels keep kSmallTiles.
     // ECFFT_SMALL_TILES_MAX / ECFFT_SMALL_LOW_MAX: A/B knobs for both.
     unsigned small_tiles_max() const {
-        static const int v = getenv("ECFFT_SMALL_TILES_MAX") ? atoi(getenv("ECFFT_SMALL_TILES_MAX")) : -1;
+        static const int v = ab_env("ECFFT_SMALL_TILES_MAX") ? atoi(ab_env("ECFFT_SMALL_TILES_MAX")) : -1;
         return v >= 0 ? (unsigned)v : (in_halves_ ? kSmallTiles : 2 * kSmallTiles);
     }
     bool small_launch(size_t total) const { return sizeof(E) == 32 && (total >> kLogLow) < small_tiles_max() && total >= ((size_t)1 << kLogLowSmall); }
-    static unsigned small_low_max() { static const unsigned v = getenv("ECFFT_SMALL_LOW_MAX") ? (unsigned)atoi(getenv("ECFFT_SMALL_LOW_MAX")) : kSmallTiles; return v; }
+    static unsigned small_low_max() { static const unsigned v = ab_env("ECFFT_SMALL_LOW_MAX") ? (unsigned)atoi(ab_env("ECFFT_SMALL_LOW_MAX")) : kSmallTiles; return v; }
     unsigned log_low_for(size_t total) const { return sizeof(E) == 32 && (total >> kLogLow) < small_low_max() && total >= ((size_t)1 << kLogLowSmall) && !ef_small_off_ ? kLogLowSmall : kLogLow; }
 
     // FFTree::exit (src/fftree.rs:227-230): n evaluations -> n coefficients.
@@ -2087,22 +2109,22 @@ private:
     const Tree* ovr_tree_ = nullptr; const ShardSet* ovr_set_ = nullptr;   // temporary share of one tree (sharded EXIT build)
     mutable double tblw_ = 1.0;     // weight of table bytes in the algorithmic-byte accounting (see enter())
     mutable std::map<uint64_t, TE*> full_cyc_; mutable size_t full_cyc_bytes_ = 0;   // compact cyclic tables of a FULL context (full_cyclic_table)
-    bool full_cyc_off_ = getenv("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
+    bool full_cyc_off_ = ab_env("ECFFT_NO_FULL_CYCLIC") != nullptr;      // A/B switch: one-stage launches with stride-P table reads
     // bit 0: ENTER levels 1..5, bit 1: EXIT levels 5..1 as one 32-point map (low32).  OFF by default: measured on MI355X (profiles/r04/low32_ab.txt)
     // the 32-point phase costs what it removes — level 5 is four 16-point phases + five pointwise steps (~35 us per tile), the phase
     // streams 1 MiB of matrices per tile and runs twice the MFMAs of low16 (k_exit_low 1.63 -> 1.65-1.69 ms, k_enter_low 0.66 -> 0.66)
-    unsigned low32_mask_ = getenv("ECFFT_LOW32") ? (unsigned)atoi(getenv("ECFFT_LOW32")) : 0u;
-    bool low16_off_ = getenv("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
-    bool mfma_off_ = getenv("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
-    unsigned small_min_logc_ = getenv("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(getenv("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
+    unsigned low32_mask_ = ab_env("ECFFT_LOW32") ? (unsigned)atoi(ab_env("ECFFT_LOW32")) : 0u;
+    bool low16_off_ = ab_env("ECFFT_NO_LOW16") != nullptr;             // A/B switch: the four lowest ENTER / EXIT levels as VALU sweeps
+    bool mfma_off_ = ab_env("ECFFT_NO_MFMA") != nullptr;                // A/B switch: innermost stages on the VALU instead of the matrix cores
+    unsigned small_min_logc_ = ab_env("ECFFT_SMALL_MIN_LOGC") ? (unsigned)atoi(ab_env("ECFFT_SMALL_MIN_LOGC")) : 1u;   // log2 of the shortest column-tile row of a small launch (rows of 2 elements: 7 stages in one pass; A/B knob)
     bool in_halves_ = false;                                            // enqueueing the two-halves schedule of one transform (caller holds lock())
     Tree pair_full_{}; bool have_pair_full_ = false;                    // EXIT-shard contexts: the full tree T_2c (c = n / world) of the redundant pair level
     // full contexts: split EXITs of at most 2^this run every top level redundantly after one all-gather (0: never) — api_exit_split
-    unsigned gather_max_log_ = getenv("ECFFT_SPLIT_GATHER_MAX_LOG") ? (unsigned)atoi(getenv("ECFFT_SPLIT_GATHER_MAX_LOG")) : 21u;
-    bool q2_split_ = getenv("ECFFT_SPLIT_Q2_SPLIT") != nullptr;        // A/B switch (full contexts): the pair level of a split EXIT as four split EXTENDs
-    bool col256_off_ = getenv("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
-    bool row256_off_ = getenv("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)
-    bool ef_small_off_ = getenv("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
+    unsigned gather_max_log_ = ab_env("ECFFT_SPLIT_GATHER_MAX_LOG") ? (unsigned)atoi(ab_env("ECFFT_SPLIT_GATHER_MAX_LOG")) : 21u;
+    bool q2_split_ = ab_env("ECFFT_SPLIT_Q2_SPLIT") != nullptr;        // A/B switch (full contexts): the pair level of a split EXIT as four split EXTENDs
+    bool col256_off_ = ab_env("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
+    bool row256_off_ = ab_env("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)
+    bool ef_small_off_ = ab_env("ECFFT_NO_SMALL_TILES") != nullptr;   // A/B switch for the small-launch tile rule
 };
 
 }  // namespace ecfft

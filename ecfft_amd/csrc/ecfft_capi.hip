@@ -5,6 +5,9 @@
 #include <new>
 #include "device_tree.h"
 #include "../../include/ecfft_hip.h"
+#ifdef ECFFT_TEST_HOOKS
+#include "../../include/ecfft_hip_hooks.h"    // test / measurement entry points: never in the shipped library
+#endif
 
 using namespace ecfft;
 
@@ -318,6 +321,7 @@ int run_table_fma(ecfft_ctx* c, DeviceChain<F>& ch, void* out, const void* x, co
 }
 }  // namespace
 
+#ifdef ECFFT_TEST_HOOKS
 template <class F>
 int run_selftest(int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
     using E = typename F::elem;
@@ -347,6 +351,7 @@ int run_selftest(int op, const void* a, const void* b, const void* c, void* out,
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc); (void)hipFree(dout);
     return ok ? ECFFT_OK : ECFFT_ERR_HIP;
 }
+#endif  // ECFFT_TEST_HOOKS
 
 // dependent chain x <- T*x + c per lane: the table multiply of the butterfly kernels with nothing else around it
 template <class F>
@@ -838,6 +843,7 @@ size_t ecfft_tree_size(const ecfft_ctx* ctx) {
     return ctx->field == ECFFT_FIELD_SECP256K1 ? ctx->secp->size() : ctx->m31->size();
 }
 int ecfft_field(const ecfft_ctx* ctx) { return ctx ? ctx->field : -1; }
+#ifdef ECFFT_TEST_HOOKS
 long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m) {
     if (!ctx || !is_pow2(m)) return -1;
     return guarded([&] {
@@ -859,6 +865,7 @@ int ecfft_test_fail_build_rank(int rank) {
     DeviceChain<M31>::test_fail_build_rank().store(rank);
     return ECFFT_OK;
 }
+#endif  // ECFFT_TEST_HOOKS
 int ecfft_ctx_trim(ecfft_ctx* ctx) {
     if (!ctx) return ECFFT_ERR_BAD_ARG;
     DeviceGuard dev(ctx->device);
@@ -941,6 +948,9 @@ int ecfft_comm_get_unique_id(void* id_out) {
     memcpy(id_out, id.internal, ECFFT_COMM_ID_BYTES);
     return ECFFT_OK;
 }
+int ecfft_comm_set_rccl_library(const char* path) {
+    return RcclApi::set_library(path) ? ECFFT_OK : ECFFT_ERR_BAD_ARG;
+}
 int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out) {
     if (!out) return ECFFT_ERR_BAD_ARG;
     *out = nullptr;
@@ -967,6 +977,7 @@ int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn 
     *out = c;
     return ECFFT_OK;
 }
+#ifdef ECFFT_TEST_HOOKS
 int ecfft_comm_init_projection(int world, int rank, int device, double delay_us, double link_gbps, ecfft_comm** out) {
     if (!out) return ECFFT_ERR_BAD_ARG;
     *out = nullptr;
@@ -978,6 +989,7 @@ int ecfft_comm_init_projection(int world, int rank, int device, double delay_us,
     *out = c;
     return ECFFT_OK;
 }
+#endif  // ECFFT_TEST_HOOKS
 void ecfft_comm_destroy(ecfft_comm* comm) {
     if (!comm) return;
     DeviceGuard dev(comm->t ? comm->t->device : 0);
@@ -1127,6 +1139,7 @@ int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n) {
     return ECFFT_OK;
 }
 
+#ifdef ECFFT_TEST_HOOKS
 int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device) {
     if (field == ECFFT_FIELD_SECP256K1) return run_selftest<Secp256k1>(op, a, b, c, out, n, device);
     if (field == ECFFT_FIELD_M31) return run_selftest<M31>(op, a, b, c, out, n, device);
@@ -1200,6 +1213,7 @@ int ecfft_ctx_low_map(const ecfft_ctx* ctx, int dir) {
     return ctx->secp->low_map(dir);
 }
 
+#endif  // ECFFT_TEST_HOOKS
 int ecfft_mul_ceiling(int field, int device, int waves_per_simd, double* mul_per_s) {
     if (field == ECFFT_FIELD_SECP256K1) return run_mul_ceiling<Secp256k1>(device, waves_per_simd, mul_per_s);
     if (field == ECFFT_FIELD_M31) return run_mul_ceiling<M31>(device, waves_per_simd, mul_per_s);

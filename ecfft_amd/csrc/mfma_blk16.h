@@ -630,6 +630,7 @@ __global__ __launch_bounds__(32) void k_blk32_seeds(const Fe256* __restrict__ cs
     const E kap = F::sub(F::mul(s, F::from_u32(128)), off);
     for (int g = 0; g < 8; ++g) Kc[o * 8 + g] = (1ull << 50) + kap.l[g];
 }
+#ifdef ECFFT_TEST_HOOKS     // kernels behind ecfft_selftest_blk16 / _blk16_small / _blk32 (include/ecfft_hip_hooks.h): test builds only
 // test hook: the 32-point phase alone on tiles of 1024 elements (grid = tiles, 512 threads), in place
 __global__ __launch_bounds__(512) void k_blk32_apply(Fe256* __restrict__ data, const uint8_t* __restrict__ Amat, const unsigned long long* __restrict__ Kc) {
     __shared__ Fe256 tile[1024];
@@ -679,5 +680,7 @@ __global__ __launch_bounds__(MODE == 1 || MODE == 4 ? 256 : 128) void k_blk16_ap
         g[tid] = Blk16::phase_n16_regs<MODE == 4 ? 4 : 2>(tile, x, Amat, Kc, tid);
     }
 }
+
+#endif  // ECFFT_TEST_HOOKS
 
 }  // namespace ecfft

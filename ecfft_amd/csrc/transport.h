@@ -12,8 +12,12 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <thread>
+#include <string>
 #include <vector>
 #include "../../include/ecfft_hip.h"
 
@@ -100,16 +104,30 @@ struct RcclApi {
         static RcclApi api = load();
         return api;
     }
+    // ecfft_comm_set_rccl_library: the library to bind instead of the mapped / system librccl.  Only before the first communicator
+    // (the binding is made once per process); returns false afterwards.  An explicit ABI call, not an environment variable: the
+    // shipped library does not dlopen a path it was not handed by its host.
+    static bool set_library(const char* path) {
+        std::lock_guard<std::mutex> g(path_mu());
+        if (bound()) return false;
+        override_path() = path ? path : "";
+        return true;
+    }
 private:
+    static std::mutex& path_mu() { static std::mutex m; return m; }
+    static std::string& override_path() { static std::string p; return p; }
+    static bool& bound() { static bool b = false; return b; }
     static RcclApi load() {
         RcclApi a;
         // reuse the copy that is already mapped (PyTorch-ROCm bundles its own librccl and has it loaded), else the system one
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        // ECFFT_RCCL_LIB: an explicit library instead (a differently named RCCL build; the tests' stand-in that lets several ranks
-        // share one GPU, tests/stub_rccl) — bound with RTLD_LOCAL so that its symbols do not shadow a librccl that is already mapped
-        if (const char* ovr = getenv("ECFFT_RCCL_LIB")) {
-            a.handle = dlopen(ovr, RTLD_NOW | RTLD_LOCAL);
-            if (!a.handle) { fprintf(stderr, "ecfft: ECFFT_RCCL_LIB=%s could not be loaded (%s)\n", ovr, dlerror()); return a; }
+        // an explicit library instead (a differently named RCCL build; the tests' stand-in that lets several ranks share one GPU,
+        // tests/stub_rccl) — bound with RTLD_LOCAL so that its symbols do not shadow a librccl that is already mapped
+        std::string ovr;
+        { std::lock_guard<std::mutex> g(path_mu()); bound() = true; ovr = override_path(); }
+        if (!ovr.empty()) {
+            a.handle = dlopen(ovr.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!a.handle) { fprintf(stderr, "ecfft: RCCL library %s could not be loaded (%s)\n", ovr.c_str(), dlerror()); return a; }
         }
         if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (a.handle) break; }
         if (!a.handle) for (const char* n : names) { a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (a.handle) break; }
@@ -135,9 +153,14 @@ public:
     bool abort() override {
         RcclApi& api = RcclApi::get();
         if (!api.CommAbort) return false;
-        aborted_.store(true);
+        aborted_.store(true);                             // no new enqueue section starts from here on
         RcclApi::Comm c = comm_.exchange(nullptr);        // ncclCommAbort also frees the communicator: no ncclCommDestroy afterwards
         if (!c) return false;
+        // an exchange may be between ncclGroupStart and ncclGroupEnd with `c` in hand: the enqueue section is host work
+        // that ends within microseconds on RCCL (what BLOCKS is the stream behind it), so wait for it to leave before the
+        // communicator is freed — bounded (0.2 s), because a transport library whose receive blocks on the HOST (the tests' stand-in)
+        // is only released by the abort itself
+        for (int spin = 0; in_enqueue_.load(std::memory_order_acquire) != 0 && spin < 2000; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
         return api.CommAbort(c) == 0;
     }
     bool init(const void* id128, int world_, int rank_, int device_) {
@@ -154,7 +177,8 @@ public:
 protected:
     bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
         RcclApi& api = RcclApi::get();
-        RcclApi::Comm c = comm_.load();
+        struct Enq { std::atomic<int>& n; explicit Enq(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_acq_rel); } ~Enq() { n.fetch_sub(1, std::memory_order_acq_rel); } } enq(in_enqueue_);
+        RcclApi::Comm c = comm_.load();                   // read INSIDE the section: abort() either sees the section or this sees no communicator
         if (aborted_.load() || !c) return false;
         const int kChar = 0;                              // ncclChar / ncclInt8
         int rc = api.GroupStart();
@@ -168,6 +192,7 @@ protected:
 private:
     std::atomic<RcclApi::Comm> comm_{nullptr};
     std::atomic<bool> aborted_{false};
+    std::atomic<int> in_enqueue_{0};
 };
 
 class CallbackTransport : public Transport {
@@ -184,6 +209,7 @@ private:
     ecfft_exchange_fn fn_; void* user_;
 };
 
+#ifdef ECFFT_TEST_HOOKS
 // ---- projection transport (measurement only) -------------------------------------------------------------------------------
 // ONE rank of a `world`-rank job timed on its own: an exchange costs what the model says — `delay_us` of latency plus the largest
 // per-peer message at `gbps` GB/s — as a kernel that spins on the constant 100 MHz wall clock ON THE CALLER'S STREAM, and moves
@@ -237,6 +263,8 @@ protected:
 private:
     double delay_us_, gbps_;
 };
+
+#endif  // ECFFT_TEST_HOOKS
 
 }  // namespace ecfft
 

@@ -141,13 +141,19 @@ class Comm:
         return Comm(h, keep=cb)
 
     @staticmethod
+    def set_rccl_library(path):
+        """ecfft_comm_set_rccl_library: the RCCL library the next (first) communicator of this process binds; None = default"""
+        from . import fftree
+        fftree._check(fftree.lib().ecfft_comm_set_rccl_library(path.encode() if path else None))
+
+    @staticmethod
     def projection(world, rank, device=0, delay_us=25.0, link_gbps=0.0):
         """MEASUREMENT ONLY (ecfft_comm_init_projection): one rank of a `world`-rank job timed on its own — exchanges cost the
         modelled time on the stream, results are meaningless"""
         from . import fftree
         L = fftree.lib()
-        L.ecfft_comm_init_projection.restype = ctypes.c_int
-        L.ecfft_comm_init_projection.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]
+        if not L.has_hooks:
+            raise fftree.EcfftError("ecfft_comm_init_projection is a measurement hook: load the hooks build (fftree.use_hooks_library())")
         h = ctypes.c_void_p()
         fftree._check(L.ecfft_comm_init_projection(world, rank, device, float(delay_us), float(link_gbps), ctypes.byref(h)))
         return Comm(h)

@@ -28,10 +28,13 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_field", "ecfft_enter", "ecfft_exit", "ecfft_extend", "ecfft_tree_table", "ecfft_build_points",
            "ecfft_device_info", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
-           "ecfft_selftest_field", "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
+           "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_selfcheck_pointwise_z", "ecfft_build_exit_shard",
-           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_test_fail_next_collective", "ecfft_selftest_blk16", "ecfft_selftest_blk16_small", "ecfft_comm_abort", "ecfft_test_fail_build_rank", "ecfft_comm_init_projection", "ecfft_selftest_blk32", "ecfft_ctx_low_map"]
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_build_exit_shard",
+           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_comm_abort", "ecfft_comm_set_rccl_library"]
+
+# include/ecfft_hip_hooks.h: only in a build with -DECFFT_TEST_HOOKS (tests/hooks/libecfft_hip_hooks.so), never in the shipped library
+HOOK_EXPORTS = ['ecfft_selftest_field', 'ecfft_selfcheck_pointwise_z', 'ecfft_test_fail_next_collective', 'ecfft_selftest_blk16', 'ecfft_selftest_blk16_small', 'ecfft_test_fail_build_rank', 'ecfft_comm_init_projection', 'ecfft_selftest_blk32', 'ecfft_ctx_low_map']
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
@@ -48,85 +51,129 @@ class EcfftError(RuntimeError):
 
 
 _lib = None
+HOOKS_LIB = os.path.join(os.path.dirname(_DIR), "tests", "hooks", "libecfft_hip_hooks.so")
 
 
-def lib():
-    """Loads (building if needed) the HIP extension.  Raises if it cannot be built or loaded."""
-    global _lib
-    if _lib is None:
-        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; load it FIRST so that this
-        # library binds to the same HIP runtime instance (two runtimes in one process cannot share the
-        # GPU: torch then reports "No HIP GPUs are available").  Plain C users link /opt/rocm directly.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        path = os.environ.get("ECFFT_LIB") or os.path.join(_DIR, "libecfft_hip.so")   # ECFFT_LIB: A/B builds for tuning
-        if not os.path.exists(path):
-            _build.build()
-        L = ctypes.CDLL(path)
-        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
-        L.ecfft_elem_size.restype, L.ecfft_elem_size.argtypes = sz, [ci]
-        L.ecfft_build_fftree.restype, L.ecfft_build_fftree.argtypes = ci, [ci, sz, ci, ctypes.POINTER(vp)]
-        L.ecfft_fftree_new.restype, L.ecfft_fftree_new.argtypes = ci, [ci, vp, sz, vp, vp, ci, ctypes.POINTER(vp)]
-        L.ecfft_ctx_destroy.restype, L.ecfft_ctx_destroy.argtypes = None, [vp]
-        L.ecfft_tree_size.restype, L.ecfft_tree_size.argtypes = sz, [vp]
-        L.ecfft_field.restype, L.ecfft_field.argtypes = ci, [vp]
-        L.ecfft_enter.restype, L.ecfft_enter.argtypes = ci, [vp, vp, vp, sz, ci, vp]
-        L.ecfft_exit.restype, L.ecfft_exit.argtypes = ci, [vp, vp, vp, sz, ci, vp]
-        L.ecfft_extend.restype, L.ecfft_extend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
-        L.ecfft_tree_table.restype, L.ecfft_tree_table.argtypes = ci, [vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
-        L.ecfft_build_points.restype, L.ecfft_build_points.argtypes = ci, [ci, sz, vp, vp, vp]
-        L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
-        L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
-        L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+def _bind(L):
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.ecfft_elem_size.restype, L.ecfft_elem_size.argtypes = sz, [ci]
+    L.ecfft_build_fftree.restype, L.ecfft_build_fftree.argtypes = ci, [ci, sz, ci, ctypes.POINTER(vp)]
+    L.ecfft_fftree_new.restype, L.ecfft_fftree_new.argtypes = ci, [ci, vp, sz, vp, vp, ci, ctypes.POINTER(vp)]
+    L.ecfft_ctx_destroy.restype, L.ecfft_ctx_destroy.argtypes = None, [vp]
+    L.ecfft_tree_size.restype, L.ecfft_tree_size.argtypes = sz, [vp]
+    L.ecfft_field.restype, L.ecfft_field.argtypes = ci, [vp]
+    L.ecfft_enter.restype, L.ecfft_enter.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+    L.ecfft_exit.restype, L.ecfft_exit.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+    L.ecfft_extend.restype, L.ecfft_extend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
+    L.ecfft_tree_table.restype, L.ecfft_tree_table.argtypes = ci, [vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
+    L.ecfft_build_points.restype, L.ecfft_build_points.argtypes = ci, [ci, sz, vp, vp, vp]
+    L.ecfft_device_info.restype, L.ecfft_device_info.argtypes = ci, [ci, ctypes.c_char_p, sz]
+    L.ecfft_extend_top_cyclic.restype, L.ecfft_extend_top_cyclic.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ctypes.c_uint, ci, ci, vp]
+    L.ecfft_extend_local_block.restype, L.ecfft_extend_local_block.argtypes = ci, [vp, vp, sz, ci, ctypes.c_uint, ci, vp]
+    L.ecfft_mul_ceiling.restype, L.ecfft_mul_ceiling.argtypes = ci, [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.ecfft_elems_to_standard.restype, L.ecfft_elems_to_standard.argtypes = ci, [ci, vp, vp, sz]
+    L.ecfft_elems_from_standard.restype, L.ecfft_elems_from_standard.argtypes = ci, [ci, vp, vp, sz]
+    L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
+    L.ecfft_enter_many.restype, L.ecfft_enter_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
+    L.ecfft_exit_many.restype, L.ecfft_exit_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
+    L.ecfft_mextend.restype, L.ecfft_mextend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
+    L.ecfft_redc.restype, L.ecfft_redc.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, vp]
+    L.ecfft_modular_reduce.restype, L.ecfft_modular_reduce.argtypes = ci, [vp, vp, vp, vp, vp, sz, ci, vp]
+    L.ecfft_vanish.restype, L.ecfft_vanish.argtypes = ci, [vp, vp, vp, sz, ci, vp]
+    L.ecfft_degree.restype, L.ecfft_degree.argtypes = ci, [vp, vp, sz, ci, vp, ctypes.POINTER(sz)]
+    L.ecfft_comm_get_unique_id.restype, L.ecfft_comm_get_unique_id.argtypes = ci, [vp]
+    L.ecfft_comm_init_rank.restype, L.ecfft_comm_init_rank.argtypes = ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ecfft_comm_init_callback.restype, L.ecfft_comm_init_callback.argtypes = ci, [ci, ci, ci, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
+    L.ecfft_comm_destroy.restype, L.ecfft_comm_destroy.argtypes = None, [vp]
+    L.ecfft_comm_rank.restype, L.ecfft_comm_rank.argtypes = ci, [vp]
+    L.ecfft_comm_world.restype, L.ecfft_comm_world.argtypes = ci, [vp]
+    L.ecfft_comm_stats_enable.restype, L.ecfft_comm_stats_enable.argtypes = ci, [vp, ci]
+    L.ecfft_comm_stats_read.restype, L.ecfft_comm_stats_read.argtypes = ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
+    L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+    L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
+    L.ecfft_build_enter_shard.restype, L.ecfft_build_enter_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ecfft_build_exit_shard.restype, L.ecfft_build_exit_shard.argtypes = ci, [ci, sz, ci, vp, ctypes.POINTER(vp)]
+    L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
+    L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
+    L.ecfft_fftree_serialize.restype, L.ecfft_fftree_serialize.argtypes = ci, [vp, ci, vp, sz, ctypes.POINTER(sz)]
+    L.ecfft_fftree_deserialize.restype, L.ecfft_fftree_deserialize.argtypes = ci, [ci, vp, sz, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ecfft_tree_rational_maps.restype, L.ecfft_tree_rational_maps.argtypes = ci, [vp, vp, vp]
+    L.ecfft_ctx_trim.restype, L.ecfft_ctx_trim.argtypes = ci, [vp]
+    L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
+    L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
+    L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
+    L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
+    L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
+                                                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.ecfft_comm_set_rccl_library.restype, L.ecfft_comm_set_rccl_library.argtypes = ci, [ctypes.c_char_p]
+    L.has_hooks = hasattr(L, "ecfft_selftest_field")
+    if L.has_hooks:      # include/ecfft_hip_hooks.h (test builds only)
         L.ecfft_selftest_field.restype, L.ecfft_selftest_field.argtypes = ci, [ci, ci, vp, vp, vp, vp, sz, ci]
-        L.ecfft_mul_ceiling.restype, L.ecfft_mul_ceiling.argtypes = ci, [ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
-        L.ecfft_elems_to_standard.restype, L.ecfft_elems_to_standard.argtypes = ci, [ci, vp, vp, sz]
-        L.ecfft_elems_from_standard.restype, L.ecfft_elems_from_standard.argtypes = ci, [ci, vp, vp, sz]
-        L.ecfft_table_fma.restype, L.ecfft_table_fma.argtypes = ci, [vp, vp, vp, vp, sz, sz, ci, sz, sz, ci, ci, vp]
-        L.ecfft_enter_many.restype, L.ecfft_enter_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
-        L.ecfft_exit_many.restype, L.ecfft_exit_many.argtypes = ci, [vp, vp, vp, sz, sz, ci, vp]
-        L.ecfft_mextend.restype, L.ecfft_mextend.argtypes = ci, [vp, vp, vp, sz, ci, sz, ci, vp]
-        L.ecfft_redc.restype, L.ecfft_redc.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, vp]
-        L.ecfft_modular_reduce.restype, L.ecfft_modular_reduce.argtypes = ci, [vp, vp, vp, vp, vp, sz, ci, vp]
-        L.ecfft_vanish.restype, L.ecfft_vanish.argtypes = ci, [vp, vp, vp, sz, ci, vp]
-        L.ecfft_degree.restype, L.ecfft_degree.argtypes = ci, [vp, vp, sz, ci, vp, ctypes.POINTER(sz)]
-        L.ecfft_comm_get_unique_id.restype, L.ecfft_comm_get_unique_id.argtypes = ci, [vp]
-        L.ecfft_comm_init_rank.restype, L.ecfft_comm_init_rank.argtypes = ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]
-        L.ecfft_comm_init_callback.restype, L.ecfft_comm_init_callback.argtypes = ci, [ci, ci, ci, EXCHANGE_FN, vp, ctypes.POINTER(vp)]
-        L.ecfft_comm_destroy.restype, L.ecfft_comm_destroy.argtypes = None, [vp]
-        L.ecfft_comm_rank.restype, L.ecfft_comm_rank.argtypes = ci, [vp]
-        L.ecfft_comm_world.restype, L.ecfft_comm_world.argtypes = ci, [vp]
-        L.ecfft_comm_stats_enable.restype, L.ecfft_comm_stats_enable.argtypes = ci, [vp, ci]
-        L.ecfft_comm_stats_read.restype, L.ecfft_comm_stats_read.argtypes = ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        L.ecfft_extend_sharded.restype, L.ecfft_extend_sharded.argtypes = ci, [vp, vp, vp, vp, sz, ci, vp]
-        L.ecfft_enter_sharded.restype, L.ecfft_enter_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
-        L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
-        L.ecfft_build_enter_shard.restype, L.ecfft_build_enter_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
         L.ecfft_selfcheck_pointwise_z.restype, L.ecfft_selfcheck_pointwise_z.argtypes = ctypes.c_long, [vp, sz]
-        L.ecfft_build_exit_shard.restype, L.ecfft_build_exit_shard.argtypes = ci, [ci, sz, ci, vp, ctypes.POINTER(vp)]
-        L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
-        L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
-        L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
-        L.ecfft_fftree_serialize.restype, L.ecfft_fftree_serialize.argtypes = ci, [vp, ci, vp, sz, ctypes.POINTER(sz)]
-        L.ecfft_fftree_deserialize.restype, L.ecfft_fftree_deserialize.argtypes = ci, [ci, vp, sz, ci, ci, ci, ctypes.POINTER(vp)]
-        L.ecfft_tree_rational_maps.restype, L.ecfft_tree_rational_maps.argtypes = ci, [vp, vp, vp]
-        L.ecfft_ctx_trim.restype, L.ecfft_ctx_trim.argtypes = ci, [vp]
         L.ecfft_test_fail_next_collective.restype, L.ecfft_test_fail_next_collective.argtypes = ci, [vp]
         L.ecfft_test_fail_build_rank.restype, L.ecfft_test_fail_build_rank.argtypes = ci, [ci]
         L.ecfft_selftest_blk16.restype, L.ecfft_selftest_blk16.argtypes = ci, [vp, vp, vp, sz, ci]
         L.ecfft_selftest_blk16_small.restype, L.ecfft_selftest_blk16_small.argtypes = ci, [vp, vp, vp, sz, ci, ci]
         L.ecfft_selftest_blk32.restype, L.ecfft_selftest_blk32.argtypes = ci, [vp, vp, vp, sz, ci]
         L.ecfft_ctx_low_map.restype, L.ecfft_ctx_low_map.argtypes = ci, [vp, ci]
-        L.ecfft_device_copy.restype, L.ecfft_device_copy.argtypes = ci, [vp, vp, sz, ci]
-        L.ecfft_shader_clock.restype, L.ecfft_shader_clock.argtypes = ci, [ci, ci, ctypes.POINTER(ctypes.c_double)]
-        L.ecfft_profile_enable.restype, L.ecfft_profile_enable.argtypes = ci, [vp, ci]
-        L.ecfft_profile_classes.restype, L.ecfft_profile_classes.argtypes = ci, []
-        L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
-                                                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        _lib = L
+        L.ecfft_comm_init_projection.restype = ci
+        L.ecfft_comm_init_projection.argtypes = [ci, ci, ci, ctypes.c_double, ctypes.c_double, ctypes.POINTER(vp)]
+    return L
+
+
+def _load(path):
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; load it FIRST so that this
+    # library binds to the same HIP runtime instance (two runtimes in one process cannot share the
+    # GPU: torch then reports "No HIP GPUs are available").  Plain C users link /opt/rocm directly.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    return _bind(ctypes.CDLL(path))
+
+
+def lib():
+    """Loads (building if needed) the HIP extension — the SHIPPED library unless ECFFT_LIB names another build (tuning variants;
+    a variable of this Python mirror, not of the C library).  Raises if it cannot be built or loaded."""
+    global _lib
+    if _lib is None:
+        path = os.environ.get("ECFFT_LIB") or os.path.join(_DIR, "libecfft_hip.so")
+        if not os.path.exists(path):
+            _build.build()
+        _lib = _load(path)
     return _lib
+
+
+class use_library:
+    """`with use_library(path):` — every call of this module goes to that build of the library for the duration (tests and
+    measurement tools: the hooks build, tests/hooks/libecfft_hip_hooks.so).  Contexts and communicators must be created AND used
+    inside the same block: a handle belongs to the library instance that made it."""
+    _loaded = {}
+
+    def __init__(self, path):
+        self.path = os.path.abspath(path)
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        if self.path not in use_library._loaded:
+            use_library._loaded[self.path] = _load(self.path)
+        _lib = use_library._loaded[self.path]
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
+
+
+def use_hooks_library():
+    """the hooks build (include/ecfft_hip_hooks.h), built on demand by tests/hooks/build_hooks.py"""
+    if not os.path.exists(HOOKS_LIB) or _build.stale(HOOKS_LIB):
+        _build.build(out=HOOKS_LIB, defines=("ECFFT_TEST_HOOKS",))
+    return use_library(HOOKS_LIB)
 
 
 def _check(rc):

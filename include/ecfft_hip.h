@@ -77,9 +77,6 @@ void ecfft_ctx_destroy(ecfft_ctx* ctx);
 
 size_t ecfft_tree_size(const ecfft_ctx* ctx);   /* number of leaves of the top tree */
 int ecfft_field(const ecfft_ctx* ctx);
-/* test hook: entries of z0_s1 / z1_s0 of the subtree with m leaves (built as the reference does, src/fftree.rs:386-397) that
- * differ from the pointwise isogeny-chain formula the sharded builds use; 0 = identical, -1 = error */
-long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m);
 size_t ecfft_ctx_device_bytes(const ecfft_ctx* ctx);   /* HBM the context holds between calls: tables + transform scratch + pooled temporaries (+ gathered cyclic tables) */
 /* The algorithm wrappers (ecfft_redc, ecfft_vanish, ecfft_degree, the sharded transforms ...) keep their temporaries in a
  * per-context pool between calls; the pool is capped (idle blocks beyond twice the transform scratch are freed at the end of a
@@ -150,18 +147,16 @@ typedef int (*ecfft_exchange_fn)(void* user, int n_send, const int* send_peer, c
                                  int n_recv, const int* recv_peer, void* const* recv_ptr, const size_t* recv_bytes, void* stream);
 int ecfft_comm_get_unique_id(void* id_out);                                                      /* ECFFT_COMM_ID_BYTES bytes */
 int ecfft_comm_init_rank(const void* id, int world, int rank, int device, ecfft_comm** out);
+/* The RCCL library ecfft_comm_get_unique_id / ecfft_comm_init_rank bind (dlopen, RTLD_LOCAL) instead of the copy already mapped into
+ * the process or /opt/rocm/lib/librccl.so: a differently named RCCL build, or the tests' stand-in (tests/stub_rccl).  NULL or "" =
+ * default.  Must precede the first communicator of the process (the binding is made once): ECFFT_ERR_BAD_ARG afterwards.  The library
+ * reads no environment variable for this (or for anything else). */
+int ecfft_comm_set_rccl_library(const char* path);
 int ecfft_comm_init_callback(int world, int rank, int device, ecfft_exchange_fn fn, void* user, ecfft_comm** out);
-/* MEASUREMENT ONLY: one rank of a `world`-rank job timed on its own.  Every exchange with a remote peer costs delay_us + (largest
- * message of the exchange) / link_gbps GB/s as a spinning kernel on the caller's stream, and the rank's own send buffers are copied
- * into its receive buffers: the stream's timeline is that of a rank whose peers answer after exactly the modelled time; the
- * RESULTS of a sharded call on such a communicator are meaningless (tools/split_project.py: per-rank compute, exchanges, bytes and
- * exposed communication time of the split transforms without multi-GPU hardware).  link_gbps = 0: latency only. */
-int ecfft_comm_init_projection(int world, int rank, int device, double delay_us, double link_gbps, ecfft_comm** out);
 void ecfft_comm_destroy(ecfft_comm* comm);
 /* RCCL transports: ncclCommAbort — unblocks the exchanges in flight (a peer died or never arrived) and makes every later sharded
  * call on this communicator return ECFFT_ERR_HIP; may be called from another host thread than the blocked one.  ECFFT_ERR_HIP for a
- * callback transport (the host owns its exchanges).  The librccl that is bound can be chosen with the environment variable
- * ECFFT_RCCL_LIB (default: the copy already mapped into the process, else /opt/rocm/lib/librccl.so). */
+ * callback transport (the host owns its exchanges).  The librccl that is bound: ecfft_comm_set_rccl_library. */
 int ecfft_comm_abort(ecfft_comm* comm);
 int ecfft_comm_rank(const ecfft_comm* comm);
 int ecfft_comm_world(const ecfft_comm* comm);
@@ -203,11 +198,7 @@ int ecfft_extend_sharded_layout(ecfft_ctx* ctx, ecfft_comm* comm, const void* in
  * prepares its temporaries and the ranks AGREE on the outcome (one int each way, host wait) before the first exchange — if any
  * rank failed, all of them return ECFFT_ERR_HIP and none is left blocked in ncclRecv.  That first call is therefore synchronous;
  * later calls of the shape reuse the pinned temporaries, cannot fail locally and are asynchronous.  ecfft_build_exit_shard votes
- * after its local part, at every level and on its final status.  ecfft_test_fail_next_collective (test hook) makes the local
- * preparation of the context's next such call report failure. */
-int ecfft_test_fail_next_collective(ecfft_ctx* ctx);
-/* test hook, process wide: the local part of the next collective ecfft_build_exit_shard reports failure on rank `rank` (-1: off) */
-int ecfft_test_fail_build_rank(int rank);
+ * after its local part, at every level and on its final status.  (Failure injection for the tests: ecfft_hip_hooks.h, test builds only.) */
 int ecfft_enter_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* coeffs, void* evals, size_t n, void* stream);
 int ecfft_exit_sharded(ecfft_ctx* ctx, ecfft_comm* comm, const void* evals, void* coeffs, size_t n, void* stream);
 
@@ -261,29 +252,6 @@ int ecfft_profile_read(ecfft_ctx* ctx, int cls, char* name, size_t cap, uint64_t
  * reader/writer (ecfft_amd/serialize.py, reference: src/fftree.rs:507-660). */
 int ecfft_elems_to_standard(int field, const void* in, void* out, size_t n);
 int ecfft_elems_from_standard(int field, const void* in, void* out, size_t n);
-
-/* Test hook: the DEVICE field arithmetic on raw residues (plain integers < p, no Montgomery interpretation), host buffers.
- * op 0: out = a*b + c mod p   1: a*b   2: a - b   3: a + b   4 / 5: a*b + c / a*b with a taken as a TABLE constant, i.e. the
- * multiply of the butterfly kernels, result in the kernels' internal (lazy) range, not canonicalised.  Lets the tests drive the hand-written gfx950 multiply with
- * directed operands (results next to p and 2^256, carry-out of the second fold) that random data never reaches. */
-int ecfft_selftest_field(int field, int op, const void* a, const void* b, const void* c, void* out, size_t n, int device);
-
-/* Test hook (secp256k1): the matrix-core form of the innermost 16-point map (ecfft_amd/csrc/mfma_blk16.h) with an EXPLICIT map —
- * matrix256 = 16 x 16 plain residues < p, row-major [output][input]; x / out = n raw residues (n a multiple of 1024), every aligned
- * block of 16 is mapped to out_o = sum_i matrix[o][i] * x_i mod p.  Lets the tests reach the carry-out and canonicalisation
- * branches of the normalisation (identity / -1 / 0 constants, inputs next to 0, p and 2^32 + 977) that a tree's constants never hit. */
-int ecfft_selftest_blk16(const void* matrix256, const void* x, void* out, size_t n, int device);
-/* ... the SMALL-LAUNCH forms of the same map (v_mfma_i32_16x16x64_i8; 256-element tiles of the latency regime).
- * mode 1: 256-element arrays, 4 waves, LDS-resident (k_enter_low<8,256>'s low16)   2: 256-element arrays, 2 waves, two results per
- * lane (k_exit_low<8,128>'s low16)   3: 128-element arrays = 8 blocks, 2 waves, element in registers (k_exit_low<8,128>'s half-tiles)
- * 4: 256-element arrays, 4 waves, element in registers (k_stages_row256, k_enter_low<8,256>'s EXTEND cores).  n: a multiple of 256. */
-int ecfft_selftest_blk16_small(const void* matrix256, const void* x, void* out, size_t n, int mode, int device);
-/* ... the 32-point form (round 4: the five lowest ENTER / EXIT levels of the 1024-element low-level kernels as one map): matrix1024 =
- * 32 x 32 plain residues, row-major [output][input]; every aligned block of 32 of x is mapped; n a multiple of 1024. */
-int ecfft_selftest_blk32(const void* matrix1024, const void* x, void* out, size_t n, int device);
-/* measurement / test hook: which composite map the context's 1024-element low-level kernels run for the lowest levels of ENTER
- * (dir 0) / EXIT (dir 1): 32 = levels 1..5, 16 = levels 1..4, 0 = level code (secp256k1 only; A/B: ECFFT_LOW32, ECFFT_NO_LOW16) */
-int ecfft_ctx_low_map(const ecfft_ctx* ctx, int dir);
 
 /* Measurement hook: field multiplies per second of the butterfly kernels' table multiply run as a bare dependent chain
  * (x <- T*x + c per lane, `waves_per_simd` resident waves per SIMD, whole chip) — the VALU ceiling bench.py prices the hot

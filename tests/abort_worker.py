@@ -15,6 +15,7 @@ import ecfft_amd  # noqa: E402
 from ecfft_amd import fftree, distributed as D  # noqa: E402
 
 L = fftree.lib()
+D.Comm.set_rccl_library(os.environ["ECFFT_WORKER_RCCL_LIB"])          # the stand-in for librccl (tests/stub_rccl)
 if sys.argv[1] == "peer":
     h = ctypes.c_void_p()
     assert L.ecfft_comm_init_rank(ctypes.create_string_buffer(bytes.fromhex(sys.argv[2]), 128), 2, 1, 0, ctypes.byref(h)) == 0

@@ -26,6 +26,16 @@ def oracle_mod():
     return oracle
 
 
+@pytest.fixture
+def hooks_lib():
+    """the HOOKS build of the library (tests/hooks/libecfft_hip_hooks.so = the same sources with -DECFFT_TEST_HOOKS: the entry points
+    of include/ecfft_hip_hooks.h and the A/B switches read from the environment) for the duration of one test.  Everything the test
+    makes (contexts, communicators) must be made inside it — never a tree from the module-level caches."""
+    from ecfft_amd import fftree as FT
+    with FT.use_hooks_library() as L:
+        yield L
+
+
 _tree_cache = {}
 
 

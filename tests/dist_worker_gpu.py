@@ -30,11 +30,13 @@ def synth(field, n, seed):
 def main():
     # ECFFT_WORKER_RCCL=1 (multi-GPU hosts): one rank per GPU, exchanges over the real RCCL transport (grouped ncclSend / ncclRecv)
     # ECFFT_WORKER_RCCL=stub (one-GPU hosts): every rank on cuda:0, gloo for the process group, and the RcclTransport bound to the
-    # test-only stand-in library (ECFFT_RCCL_LIB = tests/stub_rccl/librccl_stub.so): the RCCL code path with world > 1
+    # test-only stand-in library (ECFFT_WORKER_RCCL_LIB = tests/stub_rccl/librccl_stub.so, handed to the library through
+    # ecfft_comm_set_rccl_library — the library itself reads no environment variable): the RCCL code path with world > 1
     stub = os.environ.get("ECFFT_WORKER_RCCL") == "stub"
     rccl = os.environ.get("ECFFT_WORKER_RCCL") == "1"
     if stub:
-        assert os.environ.get("ECFFT_RCCL_LIB"), "stub mode needs ECFFT_RCCL_LIB"
+        assert os.environ.get("ECFFT_WORKER_RCCL_LIB"), "stub mode needs ECFFT_WORKER_RCCL_LIB"
+        D.Comm.set_rccl_library(os.environ["ECFFT_WORKER_RCCL_LIB"])
         dev = 0
         dist.init_process_group("gloo")
         torch.cuda.set_device(0)

@@ -2,7 +2,7 @@
 // ncclCommInitRank, ncclCommDestroy, ncclCommAbort, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString), moving
 // bytes between PROCESSES THAT SHARE ONE GPU.  Real RCCL refuses several ranks on one device and a gpurun lease has one GPU, so
 // without this the RcclTransport code path (grouped multi-peer sends / receives, sub-group peer lists, Transport::vote, the
-// collective ecfft_build_exit_shard) has only ever run with world = 1.  Selected with ECFFT_RCCL_LIB=<path of this library>.
+// collective ecfft_build_exit_shard) has only ever run with world = 1.  Selected with ecfft_comm_set_rccl_library(<path of this library>).
 //
 // Not a performance path and not shipped: messages are staged through POSIX shared memory (device -> shm object -> device with
 // blocking hipMemcpy), one shm object per message, a small control segment (named by the unique id) carries per-pair sequence

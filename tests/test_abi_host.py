@@ -19,14 +19,46 @@ def prod():
     return ecfft_amd
 
 
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
+    return sorted(set(re.findall(r"\b(ecfft_[a-z_0-9]+)\s*\(", header)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(set(re.findall(r" T (ecfft_[a-z_0-9]+)$", out, re.M)))
+
+
 def test_library_exports_every_declared_symbol(prod):
-    header = open(os.path.join(ROOT, "include", "ecfft_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(ecfft_[a-z_0-9]+)\s*\(", header)))
+    declared = _declared("ecfft_hip.h")
     assert len(declared) >= 12
     L = prod.lib()
     for sym in declared:
         assert hasattr(L, sym), f"libecfft_hip.so does not export {sym}"
     assert sorted(prod.fftree.EXPORTS) == declared
+
+
+def test_shipped_library_has_no_test_hooks_and_reads_no_environment(prod):
+    """the reference exposes tables and three methods (src/fftree.rs:23-38, 123, 164, 227); the SHIPPED library
+    exports exactly what include/ecfft_hip.h declares — none of the test / measurement entry points of include/ecfft_hip_hooks.h —
+    and reads no environment variable (no getenv import, no ECFFT_* switch name in its strings).  The hooks build
+    (tests/hooks/libecfft_hip_hooks.so, -DECFFT_TEST_HOOKS) exports both sets."""
+    import subprocess
+    import sys
+    product = os.path.join(ROOT, "ecfft_amd", "libecfft_hip.so")
+    declared, hooks = _declared("ecfft_hip.h"), [h for h in _declared("ecfft_hip_hooks.h")]
+    hooks = sorted(set(hooks) - set(declared))
+    assert sorted(prod.fftree.HOOK_EXPORTS) == hooks and len(hooks) >= 9
+    assert _exported(product) == declared
+    und = subprocess.run(["nm", "-D", "--undefined-only", product], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    names = subprocess.run(["strings", product], capture_output=True, text=True, check=True).stdout
+    assert not re.findall(r"^ECFFT_[A-Z_0-9]+$", names, re.M)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hooks"))
+    import build_hooks
+    assert _exported(build_hooks.build()) == sorted(declared + hooks)
+    assert not prod.lib().has_hooks
 
 
 def test_elem_sizes_and_limits_without_gpu(prod):

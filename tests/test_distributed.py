@@ -68,8 +68,8 @@ def test_rccl_transport_with_several_ranks_through_the_stub_library(world):
     """round 4: the RcclTransport code path (grouped ncclSend / ncclRecv with several peers per group, sub-group peer lists of the
     split ENTER / EXIT levels, Transport::vote, the collective ecfft_build_exit_shard) with world = 2 and 4 on ONE GPU: librccl is
     replaced by a test-only stand-in (tests/stub_rccl: the entry points transport.h binds, bytes staged through POSIX shared
-    memory between the processes) selected with ECFFT_RCCL_LIB.  Same worker and checks as the real multi-GPU test."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ECFFT_WORKER_RCCL="stub", ECFFT_RCCL_LIB=_stub_rccl())
+    memory between the processes) handed to the library with ecfft_comm_set_rccl_library.  Same worker and checks as the real multi-GPU test."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", ECFFT_WORKER_RCCL="stub", ECFFT_WORKER_RCCL_LIB=_stub_rccl())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker_gpu.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -81,7 +81,7 @@ def test_comm_abort_unblocks_a_rank_whose_peer_never_arrives():
     """ecfft_comm_abort (ncclCommAbort): rank 0 of a two-rank communicator starts a split EXTEND whose peer never makes the call; a
     second host thread aborts the communicator and the blocked call returns an error instead of hanging (stub library: the peer
     process attaches and then just sleeps; tests/abort_worker.py)."""
-    env = dict(os.environ, ECFFT_RCCL_LIB=_stub_rccl(), ECFFT_STUB_RCCL_TIMEOUT_S="60")
+    env = dict(os.environ, ECFFT_WORKER_RCCL_LIB=_stub_rccl(), ECFFT_STUB_RCCL_TIMEOUT_S="60")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abort_worker.py"), "main"], env=env, capture_output=True, text=True, timeout=300)
     assert "RETURNED_ERROR" in r.stdout and "abort -> True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -292,7 +292,7 @@ def _thread_ranks(P, body):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,e,P", [("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("secp256k1", 1 << 12, 2)])
-def test_full_context_fuses_its_cyclic_stages(field, e, P, monkeypatch):
+def test_full_context_fuses_its_cyclic_stages(field, e, P, monkeypatch, hooks_lib):
     """round 3: a FULL context gathers the stride-P entries of the cyclic stages into compact tables on first use, so its split
     EXTEND runs the log P cyclic stages as one fused column pass each way (no k_decompose_stage / k_recombine_stage launch) like a
     shard context does; ECFFT_NO_FULL_CYCLIC=1 keeps the one-stage launches.  All four layouts, both forms == the single-GPU EXTEND."""
@@ -432,7 +432,7 @@ def test_exit_shard_context_on_one_gpu(field, n, P):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 13, 2), ("secp256k1", 1 << 14, 4), ("m31", 1 << 18, 8)])
-def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, P, monkeypatch):
+def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, P, monkeypatch, hooks_lib):
     """round 4: the lowest top level of a split EXIT — groups of two ranks, blocks of 2n/P — is one exchange
     (each rank gets its partner's share) and the single-GPU EXIT level of the block on BOTH ranks, instead of four split EXTENDs
     with eight exchanges plus the re-blocking one.  Exchanges per EXIT: 1 + 9 (log2 P - 1) + 1 instead of 1 + 9 log2 P — checked on
@@ -482,7 +482,7 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("op", ["extend", "enter", "exit"])
-def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op):
+def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op, hooks_lib):
     """a sharded call whose local preparation fails on ONE rank (allocation failure; injected here with
     ecfft_test_fail_next_collective) must return an error on EVERY rank — the ranks vote before the first exchange — and must not
     leave the peers blocked in a receive.  The next call (nothing injected) succeeds on all ranks and is bit-exact."""
@@ -525,7 +525,7 @@ def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op):
 
 
 @pytest.mark.gpu
-def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(monkeypatch):
+def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(monkeypatch, hooks_lib):
     """the collective ecfft_build_exit_shard votes after its local part: with rank 1's local part failing, rank 0's build returns an
     error too instead of waiting for exchanges that never come"""
     import ecfft_amd
@@ -549,7 +549,7 @@ def test_collective_exit_shard_build_fails_on_every_rank_when_one_rank_fails(mon
 
 
 @pytest.mark.gpu
-def test_projection_transport_bills_the_modelled_time_per_remote_exchange():
+def test_projection_transport_bills_the_modelled_time_per_remote_exchange(hooks_lib):
     """ecfft_comm_init_projection (measurement only, tools/split_project.py): rank 0 of a 4-rank job on its own.  The exchange count and
     the bytes are those of the real split ENTER; an injected delay shows up on the stream once per exchange with a remote peer; the
     self pieces move (the output is this rank's data pushed through the launches, of the right size — its values mean nothing)."""

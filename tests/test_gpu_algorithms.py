@@ -104,7 +104,7 @@ def test_table_fma_building_block(trees, oracle_mod, field):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n", [("secp256k1", 1 << 12), ("m31", 1 << 16)])
-def test_pointwise_vanishing_tables_match_the_reference_construction(field, n):
+def test_pointwise_vanishing_tables_match_the_reference_construction(field, n, hooks_lib):
     """z0_s1 / z1_s0 of every tree of the chain: the EXTEND-based construction of the reference (src/fftree.rs:386-397, already
     compared with the oracle in test_tables_match_oracle) == the pointwise isogeny-chain formula used by the sharded builds"""
     import ecfft_amd

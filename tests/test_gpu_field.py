@@ -57,7 +57,7 @@ def directed_triples():
     return T
 
 
-def test_secp_mul_add_directed():
+def test_secp_mul_add_directed(hooks_lib):
     import ecfft_amd
     F = ecfft_amd.secp256k1
     T = directed_triples()
@@ -68,7 +68,7 @@ def test_secp_mul_add_directed():
     assert got == [(x * y) % P256 for x, y, z in T]
 
 
-def test_secp_table_multiply_directed():
+def test_secp_table_multiply_directed(hooks_lib):
     """the two-table (t, t*2^128) multiply the butterfly kernels use: canonical results on the same directed operands"""
     import ecfft_amd
     F = ecfft_amd.secp256k1
@@ -78,7 +78,7 @@ def test_secp_table_multiply_directed():
     assert unpack256(F.selftest(5, a, b)) == [(x * y) % P256 for x, y, z in T]
 
 
-def test_secp_add_sub_directed():
+def test_secp_add_sub_directed(hooks_lib):
     import ecfft_amd
     F = ecfft_amd.secp256k1
     T = directed_triples()
@@ -87,7 +87,7 @@ def test_secp_add_sub_directed():
     assert unpack256(F.selftest(3, a, b)) == [(x + y) % P256 for x, y, z in T]
 
 
-def test_m31_directed():
+def test_m31_directed(hooks_lib):
     import ecfft_amd
     F = ecfft_amd.m31
     rnd = random.Random(3)
@@ -101,7 +101,7 @@ def test_m31_directed():
     assert [int(v) for v in F.selftest(3, a, b)] == [(x + y) % P31 for x, y, z in T]
 
 
-def test_m31_lazy_table_multiply():
+def test_m31_lazy_table_multiply(hooks_lib):
     """M31's kernel-internal multiply keeps values in [0, p] (p = second representative of 0): table constant canonical,
     data and addend anywhere in [0, p], including the extreme (p-1)*p + p = p^2 that the range proof rests on"""
     import ecfft_amd
@@ -141,7 +141,7 @@ BLK16_FORMS = [0, 1, 2, 3, 4]
 
 
 @pytest.mark.parametrize("mode", BLK16_FORMS)
-def test_blk16_matrix_core_map_directed(mode):
+def test_blk16_matrix_core_map_directed(mode, hooks_lib):
     """the matrix-core form of the innermost 16-point map (mfma_blk16.h) with explicit constants: identity, -1, 0 and small
     constants put the pre-reduction value next to multiples of 2^256, so the carry-out of the fold and the canonicalisation branch
     of the normalisation run (with a tree's random-looking constants they have probability ~2^-200); results must be canonical"""
@@ -172,7 +172,7 @@ def test_blk16_matrix_core_map_directed(mode):
 
 
 @pytest.mark.parametrize("mode", BLK16_FORMS)
-def test_blk16_matrix_core_map_random_and_targeted_outputs(mode):
+def test_blk16_matrix_core_map_random_and_targeted_outputs(mode, hooks_lib):
     """random 16 x 16 maps against big-int arithmetic, plus inputs solved for so that chosen outputs are exactly 0, 1, p-1 and values
     within 2^40 of 0 and p"""
     rnd = random.Random(12)
@@ -205,7 +205,7 @@ def _blk32(T, xs):
     return unpack256(out)
 
 
-def test_blk32_matrix_core_map_directed_and_random():
+def test_blk32_matrix_core_map_directed_and_random(hooks_lib):
     """round 4: the 32-point form (the five lowest ENTER / EXIT levels of the 1024-element low-level kernels as one map,
     Blk16::phase32): identity / -1 / all-ones maps on edge operands (carry-out and canonicalisation branches of the normalisation),
     constants at the signed-digit recoding threshold, random maps against big-int arithmetic and outputs solved for 0, 1, p - 1"""

@@ -493,7 +493,7 @@ def test_fftree_new_rejects_a_leaf_that_is_a_pole():
 
 
 @pytest.mark.parametrize("log_n", [18, 20])
-def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch):
+def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch, hooks_lib):
     """round 3: for launches of >= 2^18 elements the innermost seven sweeps of every 1024-element tile run on the int8 matrix
     cores (mfma_blk16.h).  The same library with ECFFT_NO_MFMA=1 (read when a context is built) runs them as VALU sweeps: ENTER,
     EXIT of arbitrary evaluations, EXTEND both ways and the batched form must agree bit for bit, on random data and on data
@@ -524,7 +524,7 @@ def test_matrix_core_path_equals_valu_path(gpu, log_n, monkeypatch):
 
 
 @pytest.mark.parametrize("log_n", [8, 9, 12, 13, 16, 17])
-def test_small_launch_matrix_core_path_equals_valu_paths(gpu, log_n, monkeypatch):
+def test_small_launch_matrix_core_path_equals_valu_paths(gpu, log_n, monkeypatch, hooks_lib):
     """round 4: launches with fewer 1024-element tiles than CUs run on 256-element tiles; their row kernel (k_stages_row256), their
     column kernels (k_stages_col256 / _mid256 / _enter256) and the low-level kernels keep ONE element per thread in registers, and
     the stages with pair distance <= 8 — and the four lowest ENTER / EXIT levels — are 16-point maps on v_mfma_i32_16x16x64_i8
@@ -573,7 +573,7 @@ def test_small_launch_matrix_core_path_equals_valu_paths(gpu, log_n, monkeypatch
         assert np.array_equal(t_new.extend(rand[: n // 2], gpu.Moiety.S1, count=(n // 2) // e), t_r3.extend(rand[: n // 2], gpu.Moiety.S1, count=(n // 2) // e))
 
 
-def test_low16_maps_equal_the_level_code(gpu, monkeypatch):
+def test_low16_maps_equal_the_level_code(gpu, monkeypatch, hooks_lib):
     """round 3: in the 1024-element low-level kernels the four lowest ENTER / EXIT levels of every 16-block are ONE matrix-core map
     each (DeviceChain::build_low16: images of the unit vectors under the level code itself).  ECFFT_NO_LOW16=1 keeps every other
     matrix-core phase and runs those levels as VALU sweeps: both forms must agree bit for bit on random data, on byte patterns the

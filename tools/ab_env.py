@@ -5,6 +5,7 @@ import os, sys, time, statistics
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ecfft_amd
+ecfft_amd.fftree.use_hooks_library().__enter__()      # A/B switches are read by the hooks build only (tests/hooks)
 from bench import synth
 field, kv, sizes = sys.argv[1], sys.argv[2], [int(a) for a in sys.argv[3:]]
 var, val = kv.split("=")

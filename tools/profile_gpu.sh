@@ -1,8 +1,12 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of the bench command; keeps only
 # the text summaries (the rocpd databases exceed gpurun's 64 MiB return limit).
-# Usage: tools/profile_gpu.sh <tag> <dominant-kernel-substring> <hot-path launches of it = (steps+warmup)*launches_per_step> [bench args...]
+# Usage: tools/profile_gpu.sh <tag> <dominant kernel, FULL instantiation e.g. "k_stages_lds<ecfft::Secp256k1, 10>"> <hot-path launches of it = (steps+warmup)*launches_per_step> [bench args...]
+# The traced command must dispatch NOTHING of that kernel family after the timed steps: bench.py's latency_regime section (2^16 / 2^17
+# transforms after the timed loop, small <..., 0> instantiations) is switched off for it, and the kernel is matched by its full
+# instantiation — round 4's kernel_hot.json averaged the small launches instead of the timed ones.
 set -u
+export ECFFT_BENCH_NO_LATENCY=1
 TAG=$1; KERN=$2; LAST=$3; shift 3
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -22,6 +22,7 @@ import torch  # noqa: E402
 import ecfft_amd  # noqa: E402
 from ecfft_amd import distributed as D  # noqa: E402
 from ecfft_amd import fftree as FT  # noqa: E402
+FT.use_hooks_library().__enter__()      # the projection transport is a measurement hook: hooks build only (include/ecfft_hip_hooks.h)
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 delay = float(sys.argv[2]) if len(sys.argv) > 2 else 25.0
