@@ -564,7 +564,10 @@ public:
         }
         ~TempArena() { ch->arena_ = a; ch->arena_cap_ = cap; ch->arena_used_ = used; (void)hipFree(mine); }
     };
-    bool build_exit_shard(HostTree<F>&& ht, int device, Transport& tr) {
+    // min_memory: never keep the full tree T_2c — the pair level then runs as four split EXTENDs (9 exchanges instead of 1) and the
+    // context holds no tree above T_c at all.  Otherwise T_2c is kept when it fits this rank's free memory, and the ranks AGREE on
+    // the form (one rank short of memory => every rank takes the split form): ADVICE r04.
+    bool build_exit_shard(HostTree<F>&& ht, int device, Transport& tr, bool min_memory = false) {
         host_ = std::move(ht);
         N_ = host_.n; L_ = ilog2(N_); device_ = device;
         const size_t P = (size_t)tr.world;
@@ -577,17 +580,31 @@ public:
         hipStream_t s = nullptr;
         E* fdev = nullptr; E* lc_inv = nullptr;
         struct Free { E*& p; DeviceChain* ch; ~Free() { if (p) (void)hipFree(p); ch->f_ = nullptr; ch->ovr_tree_ = nullptr; ch->ovr_set_ = nullptr; } } free_f{fdev, this};
+        // Form of the pair level (groups of two ranks), agreed before anything is allocated.  Redundant (round 4): the chain goes up
+        // to T_2c and both ranks of a pair run the level on the whole 2c block from ONE exchange (api_exit_split) — for P = 2 the
+        // context is then as large as a full one.  Split: no tree above T_c, the level is four split EXTENDs on the ranks' shares (9
+        // exchanges) — the form for transforms whose tables exceed a GPU, chosen with min_memory or when T_2c does not fit the free
+        // memory of ANY rank (Transport::vote is an AND over the ranks).
+        auto arena_elems = [&](bool red) {
+            size_t total = 64 + 3 * L_ + 4096;
+            for (unsigned l = 0; l <= lc + (red ? 1u : 0u); ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
+            if (P > 2 || !red) total += log_p * (shard_set_elems(hc) + 5 * c + 256);   // P = 2, redundant: the pair level is the only top level — no share at all
+            return total + low16_elems();
+        };
+        bool want_red = !min_memory;
+        if (want_red) {
+            size_t fr = 0, tt = 0;
+            // arena + point set (2N) + transform scratch and pooled temporaries of the block level (~16 c) + headroom
+            const size_t need = (arena_elems(true) + 2 * N_ + 16 * c) * sizeof(E) + ((size_t)256 << 20);
+            if (hipMemGetInfo(&fr, &tt) != hipSuccess) { (void)hipGetLastError(); want_red = false; } else want_red = need <= fr;
+        }
+        if (const char* tr_rank = ab_env("ECFFT_TEST_PAIR_SPLIT_RANK")) if (atoi(tr_rank) == (int)rank) want_red = false;   // test builds: this rank "does not fit"
+        const bool red = tr.vote(want_red, s);
         // everything up to the first exchange is LOCAL work that can fail on one rank only (allocations, the chain up to n/P):
         // the ranks agree on its outcome before any of them enters the collective part
         auto local_part = [&]() -> bool {
             try {
-                size_t total = 64 + 3 * L_ + 4096;
-                // round 4: the chain goes up to T_2c — the lowest top level (groups of two ranks) runs REDUNDANTLY on both ranks of a
-                // pair from one exchange instead of as four split EXTENDs with nine (api_exit_split), so that level needs the whole
-                // tree and no share
-                for (unsigned l = 0; l <= lc + 1; ++l) total += (6 + 11 * kTeElems) * ((size_t)1 << l) + 1024 + blk16_elems(l);
-                if (P > 2) total += log_p * (shard_set_elems(hc) + 5 * c + 256);      // P = 2: the pair level is the only top level — no share at all
-                total += low16_elems();
+                const size_t total = arena_elems(red);
                 ECFFT_HIP_TRY(hipMalloc(&arena_, total * sizeof(E)));
                 arena_cap_ = total; arena_used_ = 0;
                 if (!upload_points(fdev, s)) return false;
@@ -595,8 +612,8 @@ public:
                 if (!ensure_scratch(2 * c)) return false;
                 create_side_streams();                                   // the rank-local ENTER / EXIT of the chunk runs the two-halves schedule too
                 trees_.assign(L_ + 1, Tree{}); sets_.assign(L_ + 1, ShardSet{});
-                for (unsigned l = 0; l <= lc + 1; ++l) if (!build_tree(l, s)) return false;
-                pair_full_ = trees_[lc + 1]; have_pair_full_ = true;     // the level-Q=2 iteration below re-points trees_[lc + 1] at the rank's shares (the distributed
+                for (unsigned l = 0; l <= lc + (red ? 1u : 0u); ++l) if (!build_tree(l, s)) return false;
+                if (red) { pair_full_ = trees_[lc + 1]; have_pair_full_ = true; }   // the level-Q=2 iteration below re-points trees_[lc + 1] at the rank's shares (the distributed
                                                                          // build of the level above still splits T_2c over the pairs); the full tables stay in the arena
                 if (!build_low16(lc, s)) return false;
                 lc_inv = take(L_);
@@ -617,7 +634,7 @@ public:
         bool ok = true;
         E *pz0[2] = {nullptr, nullptr}, *pz1[2] = {nullptr, nullptr};     // the level below: z0z0 / z1z1 _rem_xnn_s on the rank's S0 / S1 positions
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
-            if (P == 2) break;                                             // the shares of T_2c only feed the distributed build of the level above
+            if (P == 2 && red) break;                                      // redundant pair level: the shares of T_2c only feed the distributed build of the level above
             const size_t half = Q / 2, m = c * Q, stride = N_ / m;
             const unsigned lm = ilog2(m), lq = ilog2(Q), lh = ilog2(half);
             const int base = (int)((rank / Q) * Q), a = (int)rank - base, g = a / (int)half, ap = a % (int)half, subbase = base + g * (int)half;
@@ -1259,7 +1276,7 @@ public:
         // passes, no pack / unpack, no cyclic passes), and each rank keeps its own half of [u0 | v0] — which IS its chunk for the
         // local levels: 1 exchange instead of 9 (8 of the split EXTENDs + the re-blocking one) for twice the level's arithmetic.
         // EXIT-shard contexts carry T_2c for it (build_exit_shard); ECFFT_SPLIT_Q2_SPLIT=1 keeps the split form on a FULL context (A/B).
-        const bool q2_local = sh || !q2_split_;
+        const bool q2_local = sh ? have_pair_full_ : !q2_split_;      // shard contexts: the form the ranks agreed on at build time
         if (!collective_prepare(tr, 3, n, q2_local ? 1 : 0, s, [&] { cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
                                                       x0 = temp(hc); x1 = temp(hc); Rb = temp(c);
                                                       if (q2_local) { blk = temp(2 * c); Y = temp(2 * c); if (!ensure_scratch(2 * c)) throw DeviceAllocError(); } })) return false;

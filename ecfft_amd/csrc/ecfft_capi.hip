@@ -708,7 +708,7 @@ int ecfft_build_fftree(int field, size_t n, int device, ecfft_ctx** out) {
 
 namespace {
 // kind 1: EXTEND-only shard context for e = len evaluations (tree T_2e); kind 2: ENTER-only for n = len coefficients (tree T_n)
-int build_shard_ctx(int kind, int field, size_t len, int device, int world, int rank, ecfft_ctx** out, ecfft_comm* comm = nullptr) {
+int build_shard_ctx(int kind, int field, size_t len, int device, int world, int rank, ecfft_ctx** out, ecfft_comm* comm = nullptr, int flags = 0) {
     if (!out) return ECFFT_ERR_BAD_ARG;
     *out = nullptr;
     if (!is_pow2(len) || !is_pow2((size_t)(world > 0 ? world : 0))) return ECFFT_ERR_NOT_POW2;
@@ -731,7 +731,7 @@ int build_shard_ctx(int kind, int field, size_t len, int device, int world, int 
         if (!dev.ok) return (int)ECFFT_ERR_HIP;
         const bool ok = kind == 1 ? slot->build_extend_shard(std::move(ht), device, log_p, (unsigned)rank)
                       : kind == 2 ? slot->build_enter_shard(std::move(ht), device, log_p, (unsigned)rank)
-                                  : slot->build_exit_shard(std::move(ht), device, *comm->t);
+                                  : slot->build_exit_shard(std::move(ht), device, *comm->t, (flags & ECFFT_EXIT_SHARD_MIN_MEMORY) != 0);
         return ok ? (int)ECFFT_OK : (int)ECFFT_ERR_HIP;
     };
     int rc;
@@ -755,9 +755,12 @@ int build_shard_ctx(int kind, int field, size_t len, int device, int world, int 
 }  // namespace
 int ecfft_build_extend_shard(int field, size_t e, int device, int world, int rank, ecfft_ctx** out) { return build_shard_ctx(1, field, e, device, world, rank, out); }
 int ecfft_build_enter_shard(int field, size_t n, int device, int world, int rank, ecfft_ctx** out) { return build_shard_ctx(2, field, n, device, world, rank, out); }
+int ecfft_build_exit_shard_opts(int field, size_t n, int device, ecfft_comm* comm, int flags, ecfft_ctx** out) {
+    if (!comm || !comm->t || (flags & ~ECFFT_EXIT_SHARD_MIN_MEMORY)) { if (out) *out = nullptr; return ECFFT_ERR_BAD_ARG; }
+    return build_shard_ctx(3, field, n, device, comm->t->world, comm->t->rank, out, comm, flags);
+}
 int ecfft_build_exit_shard(int field, size_t n, int device, ecfft_comm* comm, ecfft_ctx** out) {
-    if (!comm || !comm->t) { if (out) *out = nullptr; return ECFFT_ERR_BAD_ARG; }
-    return build_shard_ctx(3, field, n, device, comm->t->world, comm->t->rank, out, comm);
+    return ecfft_build_exit_shard_opts(field, n, device, comm, 0, out);
 }
 
 int ecfft_fftree_new(int field, const void* leaves, size_t n, const void* map_num3, const void* map_den3, int device,

@@ -30,7 +30,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_extend_top_cyclic", "ecfft_extend_local_block",
            "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
-           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_build_exit_shard",
+           "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_build_exit_shard", "ecfft_build_exit_shard_opts",
            "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_comm_abort", "ecfft_comm_set_rccl_library"]
 
 # include/ecfft_hip_hooks.h: only in a build with -DECFFT_TEST_HOOKS (tests/hooks/libecfft_hip_hooks.so), never in the shipped library
@@ -94,6 +94,7 @@ def _bind(L):
     L.ecfft_extend_sharded_layout.restype, L.ecfft_extend_sharded_layout.argtypes = ci, [vp, vp, vp, vp, sz, ci, ci, ci, vp]
     L.ecfft_build_enter_shard.restype, L.ecfft_build_enter_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
     L.ecfft_build_exit_shard.restype, L.ecfft_build_exit_shard.argtypes = ci, [ci, sz, ci, vp, ctypes.POINTER(vp)]
+    L.ecfft_build_exit_shard_opts.restype, L.ecfft_build_exit_shard_opts.argtypes = ci, [ci, sz, ci, vp, ci, ctypes.POINTER(vp)]
     L.ecfft_ctx_device_bytes.restype, L.ecfft_ctx_device_bytes.argtypes = sz, [vp]
     L.ecfft_build_extend_shard.restype, L.ecfft_build_extend_shard.argtypes = ci, [ci, sz, ci, ci, ci, ctypes.POINTER(vp)]
     L.ecfft_exit_sharded.restype, L.ecfft_exit_sharded.argtypes = ci, [vp, vp, vp, vp, sz, vp]
@@ -230,11 +231,12 @@ class Field:
         _check(rc)
         return FFTree(self, h, device)
 
-    def build_exit_shard(self, n, comm, device=0):
-        """Sharded EXIT-only context (ecfft_build_exit_shard) — COLLECTIVE over the ranks of `comm`: the chain up to n/world plus
-        this rank's share of the top trees, z0z0_rem_xnn_s built distributed; only `exit_sharded` works on it."""
+    def build_exit_shard(self, n, comm, device=0, min_memory=False):
+        """Sharded EXIT-only context (ecfft_build_exit_shard[_opts]) — COLLECTIVE over the ranks of `comm`: the chain up to n/world plus
+        this rank's share of the top trees, z0z0_rem_xnn_s built distributed; only `exit_sharded` works on it.  min_memory: never
+        keep T_2c for the redundant pair level (ECFFT_EXIT_SHARD_MIN_MEMORY)."""
         h = ctypes.c_void_p()
-        rc = lib().ecfft_build_exit_shard(self.id, n, device, comm._h, ctypes.byref(h))
+        rc = lib().ecfft_build_exit_shard_opts(self.id, n, device, comm._h, 1 if min_memory else 0, ctypes.byref(h))
         if rc == ERR_TREE_TOO_LARGE:
             return None
         _check(rc)

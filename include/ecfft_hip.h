@@ -185,8 +185,16 @@ int ecfft_build_enter_shard(int field, size_t n, int device, int world, int rank
  * log2(world) top levels, only the rank's share of that tree: the EXTEND tables of the split over its group (both directions), its
  * entries of xnn_s, 1 / xnn_s, 1 / z0_s1 (pointwise in the point set) and of z0z0_rem_xnn_s — which is built distributed, level
  * by level, as the reference builds it (src/fftree.rs:418-452) but with the split EXIT's own operators and exchanges over `comm`.
- * No tree above T_c is materialised on any GPU.  Accepted by ecfft_exit_sharded only (same n and communicator shape). */
+ * No tree above T_c is materialised on any GPU — except T_2c for the redundant pair level, see ecfft_build_exit_shard_opts.
+ * Accepted by ecfft_exit_sharded only (same n and communicator shape). */
 int ecfft_build_exit_shard(int field, size_t n, int device, ecfft_comm* comm, ecfft_ctx** out);
+/* ... with options.  The level of the PAIRS of ranks (blocks of 2c) has two forms: REDUNDANT — each rank also keeps the full tree
+ * T_2c and both ranks of a pair run the level on the whole block from one exchange (1 exchange instead of 9, twice that level's
+ * arithmetic; at world = 2 the context is then as large as a full one) — or SPLIT over the pair's shares, with no tree above T_c
+ * anywhere.  Default (flags 0, = ecfft_build_exit_shard): redundant when T_2c fits the free memory of EVERY rank — the ranks agree
+ * before anything is allocated — split otherwise.  ECFFT_EXIT_SHARD_MIN_MEMORY: always split (the largest n a node can reach). */
+#define ECFFT_EXIT_SHARD_MIN_MEMORY 1
+int ecfft_build_exit_shard_opts(int field, size_t n, int device, ecfft_comm* comm, int flags, ecfft_ctx** out);
 /* ecfft_extend_sharded with a choice of distribution for the rank's shard on each side.  ECFFT_LAYOUT_CYCLIC: local element j'
  * is global position j' * world + rank.  A cyclic input saves the first of the four exchanges, a cyclic output the last one —
  * for hosts that chain split EXTENDs or that produce / consume the cyclic order anyway.  (BLOCK, BLOCK) == ecfft_extend_sharded. */

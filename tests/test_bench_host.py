@@ -90,14 +90,22 @@ def test_cpu_quota_parsing(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_gpus2_line_carries_the_split_object():
-    """`--gpus N > 1` (the driver's SCALE command) prints the replica line AND, under `split`, ONE ENTER+EXIT and ONE EXTEND with
-    the evaluation domain split over the ranks.  Two ranks share this box's GPU through the gloo callback
-    transport (RCCL refuses two ranks on one device); on an N-GPU node the same command runs over RCCL / xGMI."""
+@pytest.mark.parametrize("transport", ["callback", "rccl-stub"])
+def test_gpus2_headline_is_the_split_transform(transport):
+    """`--gpus N > 1` (the driver's SCALE command): the HEADLINE is the north_star partitioning — ONE ENTER+EXIT with the evaluation
+    domain split over the ranks, "scaling": "strong" — the N independent polynomials sit under `replicas`, the split EXTEND
+    (configs[3]) under `split`.  Two ranks share this box's GPU: through the gloo callback transport, and
+    through the RCCL code path bound to the test-only stand-in library (real RCCL refuses two ranks on one device); on an N-GPU
+    node the same command runs over RCCL / xGMI."""
     import socket
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, ECFFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    if transport == "rccl-stub":
+        stub = os.path.join(ROOT, "tests", "stub_rccl", "librccl_stub.so")
+        if not os.path.exists(stub):
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", stub, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp"), "-lrt"], check=True)
+        env.update(ECFFT_BENCH_TRANSPORT="rccl", ECFFT_BENCH_RCCL_LIB=stub)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "12",
            "--split-log-n", "12", "--split-log-e", "12", "--cpu-log-n", "0", "--batch", "0"]
@@ -106,9 +114,13 @@ def test_gpus2_line_carries_the_split_object():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["roofline"] is not None
+    assert d["n_gpus"] == 2 and d["headline"] == "split" and d["scaling"] == "strong" and d["roofline"] is not None
     sp = d["split"]
-    assert sp["ranks"] == 2
+    assert sp["ranks"] == 2 and sp["status"] == 0 and ("stand-in" in sp["transport"]) == (transport == "rccl-stub")
+    assert d["value"] == sp["enter_exit"]["value"] and d["ms_per_step"] == sp["enter_exit"]["ms_per_step"]
+    assert "one transform" in d["config"]["workload"] and d["config"]["split_exit"] == "gather" and d["config"]["steps"] == 2
+    rp = d["replicas"]
+    assert rp["scaling"] == "weak" and rp["value"] > 0 and "independent" in rp["parallelism"]
     for key, exch in (("enter_exit", 1), ("extend", 4)):
         o = sp[key]
         assert o["round_trip_ok"] is True and o["scaling"] == "strong" and o["n_gpus"] == 2 and o["ranks_seen_by_transport"] == 2
@@ -134,6 +146,7 @@ def test_a_stuck_split_part_costs_the_split_object_not_the_line():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"] is not None
+    assert d["scaling"] == "weak" and "replicas" not in d          # nothing promoted: the replica line stays the headline
     assert "did not finish" in d["split"]["error"] and "enter_exit" not in d["split"]
 
 

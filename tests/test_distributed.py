@@ -453,17 +453,23 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
     torch.cuda.synchronize()
     logp = P.bit_length() - 1
     counts = {}
-    for mode in ("full-gather", "full", "full-split-pairs", "shard"):
+    bytes_held = {}
+    for mode in ("full-gather", "full", "full-split-pairs", "shard", "shard-min-memory", "shard-one-rank-short"):
         # full-gather: the default of a FULL context at these sizes — one all-gather, then every top level redundantly
         if mode in ("full", "full-split-pairs"):
             monkeypatch.setenv("ECFFT_SPLIT_GATHER_MAX_LOG", "0")
         if mode == "full-split-pairs":
             monkeypatch.setenv("ECFFT_SPLIT_Q2_SPLIT", "1")
+        if mode == "shard-one-rank-short":
+            monkeypatch.setenv("ECFFT_TEST_PAIR_SPLIT_RANK", str(P - 1))
         got, nx = {}, {}
 
         def body(rank, make_comm):
             comm = make_comm()
-            ctx = F.build_exit_shard(n, comm) if mode == "shard" else F.build_fftree(n)     # the environment is read when a context is built
+            # the environment is read when a context is built.  shard-min-memory: ECFFT_EXIT_SHARD_MIN_MEMORY on every rank;
+            # shard-one-rank-short: the LAST rank reports that T_2c does not fit (test switch) — the ranks agree, every rank splits
+            ctx = F.build_exit_shard(n, comm, min_memory=(mode == "shard-min-memory")) if mode.startswith("shard") else F.build_fftree(n)
+            bytes_held[(mode, rank)] = ctx.device_bytes
             mine = x[rank * c:(rank + 1) * c].clone()
             comm.stats(True)
             got[rank] = ctx.exit_sharded(comm, mine, n)
@@ -471,12 +477,20 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
 
         _thread_ranks(P, body)
         monkeypatch.delenv("ECFFT_SPLIT_Q2_SPLIT", raising=False); monkeypatch.delenv("ECFFT_SPLIT_GATHER_MAX_LOG", raising=False)
+        monkeypatch.delenv("ECFFT_TEST_PAIR_SPLIT_RANK", raising=False)
         for rank in range(P):
             assert torch.equal(got[rank], want[rank * c:(rank + 1) * c]), (mode, rank)
         counts[mode] = nx[0]
     assert counts["full-gather"] == 1
     assert counts["full-split-pairs"] == 1 + 9 * logp
     assert counts["full"] == counts["shard"] == 1 + 9 * (logp - 1) + 1
+    # the redundant pair level is optional in a shard context.  Without T_2c the level is split again (9 exchanges) and the
+    # context holds no tree above T_n/P: at P = 2 that is where sharding saves memory at all
+    assert counts["shard-min-memory"] == counts["shard-one-rank-short"] == 1 + 9 * logp
+    for r in range(P):
+        assert bytes_held[("shard-min-memory", r)] < 0.9 * bytes_held[("shard", r)], (r, bytes_held)     # small n: fixed-size tables (low16, blk16) weigh in
+        assert bytes_held[("shard-one-rank-short", r)] <= 1.02 * bytes_held[("shard-min-memory", r)]
+    print("bytes held (rank 0):", {m: bytes_held[(m, 0)] for m in ("full", "shard", "shard-min-memory")})
     assert counts["full"] <= 0.8 * counts["full-split-pairs"] or logp > 2          # >= 20 % fewer exchange latencies (P = 2: 10 -> 2, P = 4: 19 -> 11, P = 8: 28 -> 20)
 
 
@@ -522,6 +536,43 @@ def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op, hooks
     assert first == {0: "error", 1: "error"}, first       # rank 0 did nothing wrong and still backs out, together with rank 1
     for r in range(P):
         assert torch.equal(second[r], want[r * c:(r + 1) * c]), (op, r)
+
+
+@pytest.mark.gpu
+def test_failure_injected_after_a_shape_is_agreed_waits_for_the_next_new_shape(hooks_lib):
+    """an agreed call shape never votes again (a vote is a symmetric all-rank exchange; a rank voting alone would pair its
+    4-byte messages with its peers' data messages).  The failure hook armed on rank 1 AFTER the first successful call therefore
+    leaves the second call of that shape untouched — bit-exact on both ranks — and hits the next NEW shape, where every rank votes:
+    both ranks report the error there, and the call after it succeeds."""
+    import torch
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    F = ecfft_amd.FIELDS["m31"]
+    P, n = 2, 1 << 12
+    c = n // P
+    full = F.build_fftree(2 * n)
+    x = torch.from_numpy(np.random.default_rng(12).integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+    want_ext, want_ent = full.extend(x, ecfft_amd.Moiety.S1), full.enter(x)
+    torch.cuda.synchronize()
+    L, log = FT.lib(), {0: [], 1: []}
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        ctx = F.build_fftree(2 * n)
+        mine = x[rank * c:(rank + 1) * c].clone()
+        log[rank].append(torch.equal(ctx.extend_sharded(comm, mine, n, ecfft_amd.Moiety.S1), want_ext[rank * c:(rank + 1) * c]))   # agrees the shape
+        if rank == 1:
+            assert L.ecfft_test_fail_next_collective(ctx._h) == 0
+        log[rank].append(torch.equal(ctx.extend_sharded(comm, mine, n, ecfft_amd.Moiety.S1), want_ext[rank * c:(rank + 1) * c]))   # agreed: no vote, no failure
+        try:
+            ctx.enter_sharded(comm, mine, n); log[rank].append("ok")                                                              # new shape: votes, fails everywhere
+        except FT.EcfftError:
+            log[rank].append("error")
+        log[rank].append(torch.equal(ctx.enter_sharded(comm, mine, n), want_ent[rank * c:(rank + 1) * c]))
+
+    _thread_ranks(P, body)
+    torch.cuda.synchronize()
+    assert log == {0: [True, True, "error", True], 1: [True, True, "error", True]}, log
 
 
 @pytest.mark.gpu
