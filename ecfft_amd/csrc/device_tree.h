@@ -883,16 +883,19 @@ public:
                 const bool ct = (log_ct == kLogColTileMax && (sizeof(E) == 4 || ECFFT_CT_ALL));
                 const unsigned lv = ct ? pair_spans(total, le, P.ka, log_ct, d) : 0;
                 dim3 grid((unsigned)(total >> (log_ct + lv))); size_t lds = (sizeof(E) * ((size_t)col_row_stride<E>(1u << log_c) << R)) << lv;
+                // compile-time column tiles exist for 4-byte fields only (or with ECFFT_CT_ALL): the 32-byte instantiation is not even
+                // compiled — it was dead code with 24 B of scratch in the library's code object
+                constexpr bool kCtCol = sizeof(E) == 4 || ECFFT_CT_ALL;
                 if (col256_ok(log_ct, le) && lv == 0 && (P.kind != 0 || T.c0t[srcpar])) {
                     if (P.kind == 0) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col256<F, true>), dim3((unsigned)(total >> log_ct)), dim3(256), 0, s, d, T.c0t[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c);
                     else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col256<F, false>), dim3((unsigned)(total >> log_ct)), dim3(256), 0, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c);
                 } else
                 if (P.kind == 0) {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
+                    if constexpr (kCtCol) { if (ct) { ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv); continue; } }
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, T.np0[srcpar], T.dinv[srcpar], le, P.ka, P.kb, log_c, T.c0t[srcpar], (uint32_t)lv);
                 } else {
-                    if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv);
-                    else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv);
+                    if constexpr (kCtCol) { if (ct) { ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv); continue; } }
+                    ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, T.p0[tgt], T.p1[tgt], le, P.ka, P.kb, log_c, (const TE*)nullptr, (uint32_t)lv);
                 }
             }
         }
@@ -1028,12 +1031,13 @@ public:
         dim3 grid((unsigned)(c >> log_ct)); const size_t lds = sizeof(E) * ((size_t)col_row_stride<E>(1u << log_cc) << R);
         double hsum = 0; for (unsigned k = 0; k < log_p; ++k) hsum += (double)(c >> (k + 1));
         const double bytes = sizeof(E) * (2.0 * R * c + 4.0 * hsum);
+        constexpr bool kCtCol = sizeof(E) == 4 || ECFFT_CT_ALL;              // compile-time column tiles: 4-byte fields only (see extend_core)
         if (dec) {
-            if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
-            else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+            if constexpr (kCtCol) { if (ct) { ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u); return true; } }
+            ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, true, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
         } else {
-            if (ct) ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
-            else ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
+            if constexpr (kCtCol) { if (ct) { ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, (int)kLogColTileMax>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u); return true; } }
+            ECFFT_LAUNCH(KC_COL, bytes, (k_stages_col<F, false, 0>), grid, dim3(kBlockLds), lds, s, d, ta, tb, lc, 0u, log_p - 1, log_cc, (const TE*)nullptr, 0u);
         }
         return true;
     }

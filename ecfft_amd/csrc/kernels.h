@@ -1258,6 +1258,9 @@ struct LevelTables {
 #ifndef ECFFT_N16_DEPTH2W
 #define ECFFT_N16_DEPTH2W 2     // units of constant matrices in flight in the two-wave 16x16x64 phases of k_exit_low<8,128> (1: 252 instead of 284 VGPRs, measured 0.6-1.2 % slower)
 #endif
+#ifndef ECFFT_CORE_OPAQUE_TID
+#define ECFFT_CORE_OPAQUE_TID 1  // lds_extend_core: per-call opaque thread index (no hoisting of its LDS addresses out of the callers' level loops)
+#endif
 #ifndef ECFFT_LDS_SWZ
 #define ECFFT_LDS_SWZ 1      // k_exit_low<10,512>: XOR-swizzled LDS layout of the 32-byte elements (A/B: -DECFFT_LDS_SWZ=0)
 #endif
@@ -1468,7 +1471,15 @@ __device__ __forceinline__ void reg_extend32(typename F::elem* a, uint32_t len, 
 template <class F, int BLK = kBlockLds, bool SWZ = false>      // SWZ: `a` in the XOR-swizzled layout — only the register engine (len <= BLK) reads it that way
 __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t len, uint32_t log_e, const LevelTables<F>& T, int srcpar) {
     using E = typename F::elem;
-    const uint32_t tid = threadIdx.x, npairs = len >> 1;
+    // The thread index is made opaque per call (32-byte fields): the callers run this core once per LEVEL in a loop, and with a
+    // loop-invariant tid the compiler hoists every LDS address of the matrix-core phase's swizzled layout (16 xor-ed offsets and
+    // more) out of that loop and keeps them alive across the 110-VGPR multiplies — k_enter_low<10,512> spilled 60 B for it.
+    // Recomputing them per call costs a few dozen integer instructions per level.
+    uint32_t tid_ = threadIdx.x;
+#if ECFFT_CORE_OPAQUE_TID
+    if constexpr (sizeof(E) == 32) asm volatile("" : "+v"(tid_));
+#endif
+    const uint32_t tid = tid_, npairs = len >> 1;
     const size_t e = (size_t)1 << log_e;
     const int tgt = 1 - srcpar;
     // matrix-core form of the stages with pair distance <= 8 (mfma_blk16.h): arrays of 512 (one element per thread) or of whole
