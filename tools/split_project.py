@@ -125,7 +125,8 @@ for P in worlds:
     print(f"  {P} | {res['t0']:.3f} ({res['t0_enter']:.3f} + {res['t0_exit']:.3f}) | {launches:.0f} | {nx:.0f} ({st_e['exchanges']:.0f} + {st_x['exchanges']:.0f}) | "
           f"{(st_e['bytes_sent'] + st_x['bytes_sent']) / 1e6:.1f} | {res['td']:.3f} | {exposed:.3f} | {exposed * 1e3 / max(nx, 1):.1f} | {res['tb']:.3f} | "
           f"{single / res['td']:.2f}x / {single / res['tb']:.2f}x | {exact}")
-    del esh, xsh, keep
+    del xsh
+    keep.pop("xsh", None)
     torch.cuda.empty_cache()
     # FULL context (tables replicated): the split EXIT is one all-gather + every top level redundantly (api_exit_split, n <= 2^21)
     fullc = F.build_fftree(n)
@@ -138,12 +139,31 @@ for P in worlds:
         if tag == "t0":
             comm.stats(True); runx(); stf = comm.stats(); comm.stats(False)
         del comm
-    full_rows.append((P, resf, stf))
-    del fullc
+    # the path `bench.py --gpus P` times by default: ENTER on the shard context, EXIT in the form --split-exit auto picks
+    # (n <= 2^21: the all-gather form on the full context; above: the EXIT-shard context of the first table)
+    resd = None
+    if log_n <= 21:
+        resd = {}
+        for tag, d_us, bw in (("t0", 0.0, 0.0), ("td", delay, 0.0), ("tb", delay, gbps)):
+            comm = D.Comm.projection(P, 0, 0, d_us, bw)
+            rund = lambda: fullc.exit_sharded(comm, esh.enter_sharded(comm, mine, n), n)      # noqa: E731
+            rund(); rund()
+            resd[tag] = med_ms(rund)
+            del comm
+        resd["exchanges"] = st_e["exchanges"] + stf["exchanges"]
+        resd["mb"] = (st_e["bytes_sent"] + stf["bytes_sent"]) / 1e6
+    full_rows.append((P, resf, stf, resd))
+    del fullc, esh, keep
     torch.cuda.empty_cache()
 print("(compute = rank 0's whole stream with zero-cost exchanges: local levels on the 2^%d chunk + its share of the log2 P top levels + pack / unpack;" % (log_n,))
 print(" exchanges with world = P include the self pieces of the group all-to-alls; 'exposed' is measured on the stream, not computed)")
 print("FULL contexts (tables replicated; default for n <= 2^21): split EXIT = one all-gather, then every top level redundantly on the block that contains the rank's chunk")
 print("  P | EXIT per-rank compute ms | exchanges | MB sent/rank | EXIT T(delay) ms | EXIT T(delay + bytes/bw) ms | vs single-GPU EXIT %.3f ms" % single_exit)
-for P, r, st in full_rows:
+for P, r, st, _ in full_rows:
     print(f"  {P} | {r['t0']:.3f} | {st['exchanges']:.0f} | {st['bytes_sent'] / 1e6:.1f} | {r['td']:.3f} | {r['tb']:.3f} | {single_exit / r['td']:.2f}x / {single_exit / r['tb']:.2f}x")
+if any(rd for *_, rd in full_rows):
+    print("THE PATH bench.py --gpus P TIMES (--split-exit auto): ENTER on the ENTER-shard context + EXIT as one all-gather on the full context")
+    print("  P | per-rank compute ms | exchanges | MB sent/rank | T(delay) ms | exposed ms | T(delay + bytes/bw) ms | speed-up vs 1 GPU at delay / at delay+bw")
+    for P, _, _, rd in full_rows:
+        if rd:
+            print(f"  {P} | {rd['t0']:.3f} | {rd['exchanges']:.0f} | {rd['mb']:.1f} | {rd['td']:.3f} | {rd['td'] - rd['t0']:.3f} | {rd['tb']:.3f} | {single / rd['td']:.2f}x / {single / rd['tb']:.2f}x")
