@@ -983,7 +983,19 @@ public:
         P2P snd[64], rcv[64];
         if (P > 64) return false;
         for (size_t q = 0; q < P; ++q) { snd[q] = {gbase + (int)q, from + q * piece, piece * sizeof(E)}; rcv[q] = {gbase + (int)q, to + q * piece, piece * sizeof(E)}; }
-        return tr.exchange(snd, (int)P, rcv, (int)P, s);
+        // every rank of the communicator is in such a group of P at this point of the call sequence (aligned groups): rank q sends one
+        // piece to each member of its own group — the pattern the link striping needs (small groups leave most links of the mesh idle)
+        const size_t pb = piece * sizeof(E); const int Pg = (int)P;
+        return xchg(tr, [pb, Pg](int q, std::vector<Transport::MsgDesc>& m) { const int gb = (q / Pg) * Pg; for (int j = 0; j < Pg; ++j) m.push_back({gb + j, pb}); },
+                    snd, (int)P, rcv, (int)P, s, P < (size_t)tr.world);
+    }
+    // one grouped exchange of a split transform, striped over the links of the mesh when that pays (Transport::exchange_striped);
+    // `pat(q)` = what rank q sends at this point of the call sequence.  Only inside api_enter_split / api_exit_split, which provide
+    // the relays' staging buffer; everywhere else (and with ECFFT_NO_STRIPE in a test build) the plain exchange.
+    bool xchg(Transport& tr, const Transport::PatternFn& pat, const P2P* snd, int ns, const P2P* rcv, int nr, hipStream_t s, bool worth = true) const {
+        if (!worth || !stripe_stage_ || stripe_off_) return tr.exchange(snd, ns, rcv, nr, s);
+        if (stripe_gain_ != ~(size_t)0) tr.stripe_min_gain = stripe_gain_;
+        return tr.exchange_striped(pat, snd, ns, rcv, nr, stripe_stage_, stripe_bytes_, s);
     }
     // FULL contexts: the same compact cyclic tables, gathered once per (tree, P, rank, table) from the full stage tables on first
     // use (entry i'*P + rank of stage k -> offset c - 2*(h_k/P) + i', the layout build_shard_set writes) and kept until the context
@@ -1189,7 +1201,10 @@ public:
         if ((P & (P - 1)) || c < 2 * P) return false;
         const bool sh = shard_mode();
         E *cur = nullptr, *ext = nullptr, *U = nullptr, *V = nullptr, *A = nullptr, *B = nullptr;
-        if (!collective_prepare(tr, 2, n, 0, s, [&] { cur = temp(c); ext = temp(c); U = temp(c); V = temp(c); A = temp(c); B = temp(c); })) return false;
+        E* stg = nullptr;
+        const bool stripe = P >= 4 && !stripe_off_;
+        if (!collective_prepare(tr, 2, n, stripe ? 1 : 0, s, [&] { cur = temp(c); ext = temp(c); U = temp(c); V = temp(c); A = temp(c); B = temp(c); if (stripe) stg = temp(2 * c); })) return false;
+        StripeScope stripe_scope(this, stg, 2 * c * sizeof(E));                 // relays' staging of the striped exchanges (2c elements bound every pattern below)
         bool ok = enter(in, cur, c, 1, s);
         for (size_t Q = 2; ok && Q <= P; Q *= 2) {
             const size_t half = Q / 2, m = c * Q, e = m / 2;
@@ -1199,7 +1214,9 @@ public:
             if (!ok) break;
             P2P snd[2] = {{base + 2 * ap, cur, c * sizeof(E)}, {base + 2 * ap + 1, ext, c * sizeof(E)}};
             P2P rcv[2] = {{base + a / 2, U, c * sizeof(E)}, {base + (int)half + a / 2, V, c * sizeof(E)}};
-            ok = tr.exchange(snd, 2, rcv, 2, s);
+            { const size_t cb = c * sizeof(E); const int Qi = (int)Q, hi = (int)half;
+              ok = xchg(tr, [cb, Qi, hi](int q, std::vector<Transport::MsgDesc>& m) { const int b = (q / Qi) * Qi, p = (q - b) % hi; m.push_back({b + 2 * p, cb}); m.push_back({b + 2 * p + 1, cb}); },
+                        snd, 2, rcv, 2, s); }
             // a shard context holds exactly the c entries xnn_s[i'*Q + a] of T_m, compact; a full one the whole table
             const E* xnn = trees_[ilog2(m)].xnn + (sh ? 0 : a); const size_t xs = sh ? 1 : Q;
             foreach_n(s, c, [=] __device__(size_t i) { cur[i] = F::mul_add(xnn[i * xs], V[i], U[i]); });      // :157-158
@@ -1281,9 +1298,12 @@ public:
         // local levels: 1 exchange instead of 9 (8 of the split EXTENDs + the re-blocking one) for twice the level's arithmetic.
         // EXIT-shard contexts carry T_2c for it (build_exit_shard); ECFFT_SPLIT_Q2_SPLIT=1 keeps the split form on a FULL context (A/B).
         const bool q2_local = sh ? have_pair_full_ : !q2_split_;      // shard contexts: the form the ranks agreed on at build time
-        if (!collective_prepare(tr, 3, n, q2_local ? 1 : 0, s, [&] { cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
+        E* stg = nullptr;
+        const bool stripe = P >= 4 && !stripe_off_;
+        if (!collective_prepare(tr, 3, n, (q2_local ? 1 : 0) | (stripe ? 4 : 0), s, [&] { if (stripe) stg = temp(c); cur = temp(c); e0 = temp(hc); e1 = temp(hc); t0 = temp(hc); h0 = temp(hc); h1 = temp(hc); A = temp(hc); B = temp(hc);
                                                       x0 = temp(hc); x1 = temp(hc); Rb = temp(c);
                                                       if (q2_local) { blk = temp(2 * c); Y = temp(2 * c); if (!ensure_scratch(2 * c)) throw DeviceAllocError(); } })) return false;
+        StripeScope stripe_scope(this, stg, c * sizeof(E));
         bool ok = true;
         {   // block -> (e0, e1) cyclic over all ranks: pair t = t'*P + r' of the chunk goes to rank r', slot t'
             const size_t cpp = hc / P; const unsigned lp = ilog2(P);
@@ -1304,7 +1324,8 @@ public:
                 E *pe0 = h0, *pe1 = h1;
                 P2P snd[2] = {{base + 1 - a, e0, hc * sizeof(E)}, {base + 1 - a, e1, hc * sizeof(E)}};
                 P2P rcv[2] = {{base + 1 - a, pe0, hc * sizeof(E)}, {base + 1 - a, pe1, hc * sizeof(E)}};
-                ok = tr.exchange(snd, 2, rcv, 2, s);
+                { const size_t hb = hc * sizeof(E);
+                  ok = xchg(tr, [hb](int q, std::vector<Transport::MsgDesc>& m) { m.push_back({q ^ 1, hb}); m.push_back({q ^ 1, hb}); }, snd, 2, rcv, 2, s); }
                 if (!ok) break;
                 { const size_t aa = (size_t)a, bb = (size_t)(1 - a);
                   foreach_n(s, hc, [=] __device__(size_t j) {
@@ -1330,7 +1351,9 @@ public:
             foreach_n(s, hc, [=] __device__(size_t j) { h1[j] = F::mul(xi[j * s2], F::sub(e0[j], h0[j])); });               // :215-219
             P2P snd[2] = {{base + a / 2, h0, hc * sizeof(E)}, {base + (int)half + a / 2, h1, hc * sizeof(E)}};
             P2P rcv[2] = {{base + 2 * ap, e0, hc * sizeof(E)}, {base + 2 * ap + 1, e1, hc * sizeof(E)}};
-            ok = tr.exchange(snd, 2, rcv, 2, s);
+            { const size_t hb = hc * sizeof(E); const int Qi = (int)Q, hi = (int)half;
+              ok = xchg(tr, [hb, Qi, hi](int q, std::vector<Transport::MsgDesc>& m) { const int b = (q / Qi) * Qi, aq = q - b; m.push_back({b + aq / 2, hb}); m.push_back({b + hi + aq / 2, hb}); },
+                        snd, 2, rcv, 2, s); }
         }
         if (ok) foreach_n(s, hc, [=] __device__(size_t j) { cur[2 * j] = e0[j]; cur[2 * j + 1] = e1[j]; });
         if (ok) ok = exit(cur, out, c, 1, s);
@@ -2142,6 +2165,12 @@ private:
     Tree pair_full_{}; bool have_pair_full_ = false;                    // EXIT-shard contexts: the full tree T_2c (c = n / world) of the redundant pair level
     // full contexts: split EXITs of at most 2^this run every top level redundantly after one all-gather (0: never) — api_exit_split
     unsigned gather_max_log_ = ab_env("ECFFT_SPLIT_GATHER_MAX_LOG") ? (unsigned)atoi(ab_env("ECFFT_SPLIT_GATHER_MAX_LOG")) : 21u;
+    // link striping of the big pairwise exchanges (Transport::exchange_striped): staging of the call in flight; A/B switches (test builds)
+    mutable void* stripe_stage_ = nullptr; mutable size_t stripe_bytes_ = 0;
+    struct StripeScope { const DeviceChain* ch; StripeScope(const DeviceChain* c, void* p, size_t b) : ch(c) { ch->stripe_stage_ = p; ch->stripe_bytes_ = p ? b : 0; }
+                         ~StripeScope() { ch->stripe_stage_ = nullptr; ch->stripe_bytes_ = 0; } };
+    bool stripe_off_ = ab_env("ECFFT_NO_STRIPE") != nullptr;
+    size_t stripe_gain_ = ab_env("ECFFT_STRIPE_MIN_GAIN") ? (size_t)atoll(ab_env("ECFFT_STRIPE_MIN_GAIN")) : ~(size_t)0;
     bool q2_split_ = ab_env("ECFFT_SPLIT_Q2_SPLIT") != nullptr;        // A/B switch (full contexts): the pair level of a split EXIT as four split EXTENDs
     bool col256_off_ = ab_env("ECFFT_NO_COL256") != nullptr;            // A/B switch: small column passes on the generic kernels (pair-split LDS sweeps)
     bool row256_off_ = ab_env("ECFFT_NO_ROW256") != nullptr;            // A/B switch: small row passes on the generic kernel (pair-split LDS sweeps)

@@ -495,6 +495,57 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 14, 4), ("secp256k1", 1 << 15, 8), ("m31", 1 << 18, 8)])
+def test_link_striping_of_the_pairwise_exchanges_is_bit_exact(field, n, P, monkeypatch, hooks_lib):
+    """round 5: the big PAIRWISE exchanges of a split ENTER / EXIT (the level's re-distribution, the pair level, small-group
+    all-to-alls) travel striped over every link of the mesh — slice k of a message via rank k, two grouped exchanges
+    (Transport::exchange_striped) — when that takes >= 2 MiB off the most loaded link.  Here the threshold is 0 (test switch), so
+    every eligible exchange of these small transforms is striped: results must equal the single-GPU transforms bit for bit, on
+    shard contexts and on a full context, and more exchanges must have been issued than without striping."""
+    import torch
+    import ecfft_amd
+    F = ecfft_amd.FIELDS[field]
+    c = n // P
+    full_tree = F.build_fftree(n)
+    rng = np.random.default_rng(77)
+    if field == "m31":
+        x = torch.from_numpy(rng.integers(0, 2**31 - 1, n, dtype=np.uint32).view(np.int32)).cuda()
+    else:
+        a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+        x = torch.from_numpy(a.view(np.int64)).cuda()
+    want_ev, want_co = full_tree.enter(x), full_tree.exit(x)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("ECFFT_SPLIT_GATHER_MAX_LOG", "0")              # full contexts: the split levels, not the all-gather form
+    counts = {}
+    for mode in ("plain", "striped"):
+        if mode == "striped":
+            monkeypatch.setenv("ECFFT_STRIPE_MIN_GAIN", "0")
+        else:
+            monkeypatch.setenv("ECFFT_NO_STRIPE", "1")
+        got = {}
+
+        def body(rank, make_comm):
+            comm = make_comm()
+            esh, xsh, fc = F.build_enter_shard(n, P, rank), F.build_exit_shard(n, comm), F.build_fftree(n)
+            mine = x[rank * c:(rank + 1) * c].clone()
+            comm.stats(True)
+            got[("enter", rank)] = esh.enter_sharded(comm, mine, n)
+            got[("exit", rank)] = xsh.exit_sharded(comm, mine, n)
+            got[("enter-full", rank)] = fc.enter_sharded(comm, mine, n)
+            got[("exit-full", rank)] = fc.exit_sharded(comm, mine, n)
+            got[("nx", rank)] = comm.stats()["exchanges"]
+
+        _thread_ranks(P, body)
+        monkeypatch.delenv("ECFFT_STRIPE_MIN_GAIN", raising=False); monkeypatch.delenv("ECFFT_NO_STRIPE", raising=False)
+        for r in range(P):
+            sl = slice(r * c, (r + 1) * c)
+            assert torch.equal(got[("enter", r)], want_ev[sl]) and torch.equal(got[("enter-full", r)], want_ev[sl]), (mode, r)
+            assert torch.equal(got[("exit", r)], want_co[sl]) and torch.equal(got[("exit-full", r)], want_co[sl]), (mode, r)
+        counts[mode] = got[("nx", 0)]
+    assert counts["striped"] > counts["plain"], counts
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("op", ["extend", "enter", "exit"])
 def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op, hooks_lib):
     """a sharded call whose local preparation fails on ONE rank (allocation failure; injected here with
