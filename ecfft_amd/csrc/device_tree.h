@@ -743,10 +743,14 @@ public:
 #endif
     static constexpr unsigned kLogTileMax = (sizeof(E) == 32) ? ECFFT_LOG_TILE_BYTES - 5 : ECFFT_LOG_TILE_BYTES - 2;   // 32 KiB LDS tiles by default (A/B on MI355X: 512 threads x 32 KiB beat 64 KiB tiles by ~5%)
 #ifndef ECFFT_COL_STAGES
-#define ECFFT_COL_STAGES 8
-#endif
+#define ECFFT_COL_STAGES 9      // round 5: 9 (was 8) together with ECFFT_COL_MIN_LOGC 1 — the nine column stages of an EXTEND of 2^19 (every core of
+#endif                          // level 20) run as ONE pass on tiles of 2^9 rows x 2 elements instead of two passes of 5 + 4 stages: 2^20 -1.4 %, 2^21 -0.8 %
 #ifndef ECFFT_LOG_COL_TILE_BYTES
 #define ECFFT_LOG_COL_TILE_BYTES 15
+#endif
+#ifndef ECFFT_COL_MIN_LOGC
+#define ECFFT_COL_MIN_LOGC 1     // log2 of the shortest column-tile row of a full-size launch (2: rows of >= 4 elements = 128 B, rounds 1-4; 1: 64-byte rows
+                                 // are accepted where they save a whole pass, i.e. for exactly nine column stages)
 #endif
 #ifndef ECFFT_COL_STAGES_4B
 #define ECFFT_COL_STAGES_4B 9
@@ -784,7 +788,7 @@ public:
         if (k_first > k_begin) {                                              // balanced groups of <= kColStages stages
             unsigned log_ct0 = tz < kLogColTileMax ? tz : kLogColTileMax;
             if (small && log_ct0 > kLogLowSmall) log_ct0 = kLogLowSmall;
-            const unsigned minc = (small && log_ct0 == kLogLowSmall) ? small_min_logc_ : 2u;
+            const unsigned minc = (small && log_ct0 == kLogLowSmall) ? small_min_logc_ : (unsigned)ECFFT_COL_MIN_LOGC;
             unsigned rmax = kColStages < log_ct0 - minc ? kColStages : log_ct0 - minc;    // keep rows >= 4 elements (128 B)
             if (rmax < 1) rmax = 1;
             unsigned ncol = k_first - k_begin, ngrp = (ncol + rmax - 1) / rmax;

@@ -47,6 +47,10 @@ public:
         check(ecfft_comm_init_rank(id.data(), world, rank, device, &c));
         return Comm(c);
     }
+    // the RCCL library the first communicator of the process binds (ecfft_comm_set_rccl_library); "" / nullptr = the default
+    static void set_rccl_library(const char* path) { check(ecfft_comm_set_rccl_library(path)); }
+    // ncclCommAbort: unblocks exchanges in flight (from another host thread); later sharded calls on this communicator fail
+    bool abort() { return ecfft_comm_abort(c_) == ECFFT_OK; }
     int rank() const { return ecfft_comm_rank(c_); }
     int world() const { return ecfft_comm_world(c_); }
     ecfft_comm* raw() const { return c_; }
@@ -90,9 +94,10 @@ public:
         return FFTree(c);
     }
     // sharded EXIT-only context (ecfft_build_exit_shard), a COLLECTIVE build over `comm`: only exit_sharded works on it
-    static std::optional<FFTree> build_exit_shard(size_t n, const Comm& comm, int device = 0) {
+    // min_memory: never keep the full tree T_2n/world for the redundant pair level (ECFFT_EXIT_SHARD_MIN_MEMORY)
+    static std::optional<FFTree> build_exit_shard(size_t n, const Comm& comm, int device = 0, bool min_memory = false) {
         ecfft_ctx* c = nullptr;
-        int rc = ecfft_build_exit_shard(F::id, n, device, comm.raw(), &c);
+        int rc = ecfft_build_exit_shard_opts(F::id, n, device, comm.raw(), min_memory ? ECFFT_EXIT_SHARD_MIN_MEMORY : 0, &c);
         if (rc == ECFFT_ERR_TREE_TOO_LARGE) return std::nullopt;
         check(rc);
         return FFTree(c);
