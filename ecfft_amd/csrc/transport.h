@@ -113,7 +113,9 @@ public:
         size_t mD = 0, m1 = 0, m2 = 0, need = 0;
         for (size_t i = 0; i < D.size(); ++i) { if (D[i] > mD) mD = D[i]; if (S1[i] > m1) m1 = S1[i]; if (S2[i] > m2) m2 = S2[i]; }
         bool any = false;
-        for (const GM& g : gm) { any = any || g.striped; if (g.striped && g.src != me && g.dst != me) need += g.len; }
+        // the staging bound is rank-independent on purpose (every rank must take the same decision): all relayed slices together, of
+        // which a rank stages at most its 1/world-th ... world-th part
+        for (const GM& g : gm) { any = any || g.striped; if (g.striped) need += g.len; }
         if (!any || mD <= m1 + m2 || mD < m1 + m2 + stripe_min_gain || need > stage_bytes) return exchange(sends, ns, recvs, nr, s);
         // phase 1: slice k of every striped message to rank k (slice `dst` lands in place, slice `src` waits for phase 2); messages that
         // are not striped (small, self) whole.  Between one pair of ranks the messages match in the order given: both sides walk the
