@@ -23,16 +23,16 @@ _gpu_trees = {}
 
 
 class _OracleHeadline:
-    """The CPU oracle at the HEADLINE size (secp256k1 n = 2^20, BASELINE.json configs[2]) and at 2^19 (the smallest size that
-    runs the two-halves schedule), computed ONCE per session on background host threads while the other GPU tests run: the
-    oracle's 2^20 tree takes minutes to build, its subtree chain (src/fftree.rs:465-482) serves the 2^19 transforms too.
-    Inputs are seeded; `get()` joins and returns the dict of expected outputs (the expected side of src/lib.rs:108-152)."""
-    LOG_N = 20
+    """The CPU oracle at the HEADLINE sizes, computed ONCE per session on background host threads while the other GPU tests run (the
+    oracle is called through ctypes, which releases the GIL): secp256k1 n = 2^20 (BASELINE.json configs[2]) and 2^19 (the smallest
+    size that runs the two-halves schedule) on the oracle's 2^20 tree — minutes to build; its subtree chain (src/fftree.rs:465-482)
+    serves the 2^19 transforms — and, since round 5, M31 n = 2^24 (configs[4]) and 2^22 on its 2^24 tree.  Inputs are seeded;
+    `get()` joins and returns {log_n: expected outputs} (the expected side of src/lib.rs:108-152, 239-264)."""
 
-    def __init__(self, oracle_mod):
+    def __init__(self, oracle_mod, field, log_top, sizes):
         import threading
-        self.o = oracle_mod
-        self.F = oracle_mod.field("secp256k1")
+        self.o, self.field, self.log_top, self.sizes = oracle_mod, field, log_top, sizes
+        self.F = oracle_mod.field(field)
         self.res, self.err = {}, []
         self.th = threading.Thread(target=self._run, daemon=True)
         self.th.start()
@@ -52,8 +52,8 @@ class _OracleHeadline:
     def _run(self):
         import threading
         try:
-            ot = self.F.build_fftree(1 << self.LOG_N)
-            th = [threading.Thread(target=self._size, args=(ot, ln)) for ln in (self.LOG_N, self.LOG_N - 1)]
+            ot = self.F.build_fftree(1 << self.log_top)
+            th = [threading.Thread(target=self._size, args=(ot, ln)) for ln in self.sizes]
             [t.start() for t in th]
             [t.join() for t in th]
         except Exception as e:  # pragma: no cover
@@ -65,14 +65,15 @@ class _OracleHeadline:
         return self.res
 
 
-_oracle_headline = []
+_oracle_headline = {}
 
 
 @pytest.fixture(scope="module")
 def oracle_headline(oracle_mod, gpu):
     if not _oracle_headline:
-        _oracle_headline.append(_OracleHeadline(oracle_mod))
-    return _oracle_headline[0]
+        _oracle_headline["secp256k1"] = _OracleHeadline(oracle_mod, "secp256k1", 20, (20, 19))
+        _oracle_headline["m31"] = _OracleHeadline(oracle_mod, "m31", 24, (24, 22))
+    return _oracle_headline
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -359,8 +360,8 @@ def test_secp_headline_sizes_vs_oracle(gpu, gpu_tree, oracle_mod, oracle_headlin
     2^19 runs both on its own 2^19 context and as a length-2^19 call on the 2^20 context (subtree_with_size, src/fftree.rs:489-496:
     the same leaves, every second one of the big tree).  The oracle side is computed on background threads (_OracleHeadline)."""
     n = 1 << log_n
-    want = oracle_headline.get()[log_n]
-    c, r = oracle_headline.inputs(log_n)
+    want = oracle_headline["secp256k1"].get()[log_n]
+    c, r = oracle_headline["secp256k1"].inputs(log_n)
     t = gpu_tree("secp256k1", n if own_tree else 1 << 20)
     ev = t.enter(c)
     assert np.array_equal(ev, want["enter"])
@@ -375,6 +376,25 @@ def test_secp_headline_sizes_vs_oracle(gpu, gpu_tree, oracle_mod, oracle_headlin
     evd = t.enter(d)
     assert np.array_equal(evd.cpu().numpy().view(np.uint64), want["enter"])
     assert np.array_equal(t.exit(evd).cpu().numpy().view(np.uint64), c)
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_m31_config5_sizes_vs_oracle(gpu, gpu_tree, oracle_mod, oracle_headline, log_n):
+    """round 5: M31 n = 2^24 (BASELINE.json configs[4]: ENTER on one GPU) and 2^22 against the CPU oracle ELEMENT FOR ELEMENT — ENTER, EXIT
+    of arbitrary evaluations, EXTEND both ways.  2^24 is where the paired-span column passes (two vectors per workgroup), the
+    8192-element register engine and the two-halves schedule all run; until now it was held by ~1 000 Horner leaves and properties.
+    The oracle side (its 2^24 tree, whose subtree chain serves 2^22) is computed on background threads (_OracleHeadline)."""
+    n = 1 << log_n
+    want = oracle_headline["m31"].get()[log_n]
+    c, r = oracle_headline["m31"].inputs(log_n)
+    t = gpu_tree("m31", n)
+    ev = t.enter(c)
+    assert np.array_equal(ev, want["enter"])
+    assert np.array_equal(t.exit(ev), c)
+    assert np.array_equal(t.exit(r), want["exit"])
+    h = r[: n // 2]
+    assert np.array_equal(t.extend(h, gpu.Moiety.S1), want["ext_s1"])
+    assert np.array_equal(t.extend(h, gpu.Moiety.S0), want["ext_s0"])
 
 
 def test_config4_extend_2e22(gpu, gpu_tree, oracle_mod):
