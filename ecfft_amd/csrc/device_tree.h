@@ -106,6 +106,9 @@ private:
          hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);               \
          if (prof_.on) prof_.end(stream); } while (0)
 
+#ifdef ECFFT_EXP_HALF_DELAY_US
+__global__ void k_exp_delay_us(unsigned long long ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
+#endif
 template <class F>
 class DeviceChain {
 public:
@@ -1495,6 +1498,9 @@ public:
         E* Y = base; E* sA = base + n; E* sB = sA + scratch_need(n / 2, depth - 1);
         exit_levels(in, Y, n, 1, s, sA, ln, ln);
         (void)hipEventRecord(ev_fork_[me], s); (void)hipStreamWaitEvent(s2, ev_fork_[me], 0);
+#ifdef ECFFT_EXP_HALF_DELAY_US      // experiment: the second half-stream starts this much later (its k_exit_low then runs after the first one's)
+        hipLaunchKernelGGL(k_exp_delay_us, dim3(1), dim3(1), 0, s2, (unsigned long long)(ECFFT_EXP_HALF_DELAY_US) * 100ull);
+#endif
         exit_rec(Y, out, n / 2, s, sA, depth - 1, next_side);
         double w = tblw_; tblw_ = 0.0; exit_rec(Y + n / 2, out + n / 2, n / 2, s2, sB, depth - 1, next_side); tblw_ = w;
         (void)hipEventRecord(ev_join_[me], s2); (void)hipStreamWaitEvent(s, ev_join_[me], 0);
