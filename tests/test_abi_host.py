@@ -88,6 +88,7 @@ def test_shard_context_argument_errors_without_gpu(prod):
     assert L.ecfft_build_extend_shard(0, 1 << 35, 0, 2, 0, C.byref(h)) == F.ERR_TREE_TOO_LARGE   # T_2e beyond the curve's 2-adicity
     assert L.ecfft_build_enter_shard(1, 1 << 29, 0, 2, 0, C.byref(h)) == F.ERR_TREE_TOO_LARGE
     assert L.ecfft_build_exit_shard(0, 1 << 12, 0, None, C.byref(h)) == F.ERR_BAD_ARG      # no communicator
+    assert L.ecfft_build_exit_shard_opts(0, 1 << 12, 0, None, 1, C.byref(h)) == F.ERR_BAD_ARG
 
 
 def test_no_cpu_fallback(prod):
@@ -131,3 +132,24 @@ def test_generated_multiply_is_in_sync_with_its_generator(tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_mulmod_asm.py")], check=True, env=env, capture_output=True)
     with open(os.path.join(root, "ecfft_amd", "csrc", "secp256k1_mul_gfx950.inc")) as f:
         assert f.read() == out.read_text()
+
+
+def test_rccl_library_can_only_be_chosen_before_the_first_communicator():
+    """ecfft_comm_set_rccl_library (round 5: an ABI call instead of an environment variable): accepted until the library is bound,
+    ECFFT_ERR_BAD_ARG afterwards; a path that cannot be loaded makes communicator creation fail loudly instead of falling back.
+    Runs in a subprocess (the binding is once per process)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys; sys.path.insert(0, %r)\n"
+        "from ecfft_amd import fftree as FT\n"
+        "L = FT.lib()\n"
+        "assert L.ecfft_comm_set_rccl_library(b'/nonexistent/librccl.so') == 0\n"
+        "assert L.ecfft_comm_set_rccl_library(None) == 0\n"
+        "assert L.ecfft_comm_set_rccl_library(b'/nonexistent/librccl.so') == 0\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "assert L.ecfft_comm_get_unique_id(buf) != 0          # binds: the named library cannot be loaded -> error, no silent fallback\n"
+        "assert L.ecfft_comm_set_rccl_library(None) == FT.ERR_BAD_ARG      # bound: too late\n"
+        "print('RCCL_LIB_OK')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RCCL_LIB_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
