@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ecfft_amd
+ecfft_amd.fftree.use_hooks_library().__enter__()      # ECFFT_NO_MFMA is read by the hooks build only (tests/hooks)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 P = ecfft_amd.FIELDS["secp256k1"]
