@@ -347,24 +347,28 @@ static fftree* derive_subtree(const fe* f, size_t leaves, const ratmap* maps, in
 }
 
 /* from_tree (src/fftree.rs:318-463); takes ownership of f */
+/* TEST INFRASTRUCTURE switch (per thread): build ONLY what extend_impl (src/fftree.rs:72-120) reads of ONE tree — the f layers and the
+ * recombine / decompose matrices (:341-363) — and none of the subtree chain or the xnn / z tables.  An EXTEND of e evaluations runs on
+ * T_2e alone (:123-126), so BASELINE configs[3] (e = 2^22 on T_2^23) can be checked element for element without the quarter of an hour
+ * the whole 2^23 chain would take.  The matrix code below is the same code either way. */
+static __thread int ora_extend_only = 0;
 static fftree* from_tree(fe* f, size_t n, const ratmap* maps, int nmaps) {
     fftree* t = (fftree*)calloc(1, sizeof(fftree));
     t->n = n; t->f = f;
     t->nmaps = nmaps;
     t->maps = (ratmap*)calloc(nmaps ? nmaps : 1, sizeof(ratmap));
     if (nmaps) memcpy(t->maps, maps, nmaps * sizeof(ratmap));
-    t->subtree = derive_subtree(f, n, maps, nmaps);            /* :319 */
+    if (!ora_extend_only) t->subtree = derive_subtree(f, n, maps, nmaps);            /* :319 */
     const fe* s = f + n;                                       /* f_layers[0] */
     uint64_t nn = n / 2, nnnn = n / 4;                         /* :322-323 */
 
     fe* xnnnn_s = fe_alloc(n); fe* xnnnn_s_inv = fe_alloc(n);  /* :328-330 */
     t->xnn_s = fe_alloc(n); t->xnn_s_inv = fe_alloc(n);        /* :331-333 */
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = 0; i < (ora_extend_only ? 0 : n); ++i) {
         xnnnn_s[i] = fe_pow_u64(s[i], nnnn); xnnnn_s_inv[i] = xnnnn_s[i];
         t->xnn_s[i] = fe_pow_u64(s[i], nn); t->xnn_s_inv[i] = t->xnn_s[i];
     }
-    batch_inversion(xnnnn_s_inv, n);
-    batch_inversion(t->xnn_s_inv, n);
+    if (!ora_extend_only) { batch_inversion(xnnnn_s_inv, n); batch_inversion(t->xnn_s_inv, n); }
 
     size_t hn = n / 2;
     fe* s0 = fe_alloc(hn); fe* s1 = fe_alloc(hn);              /* :336 */
@@ -395,6 +399,7 @@ static fftree* from_tree(fe* f, size_t n, const ratmap* maps, int nmaps) {
         }
     }
 
+    if (ora_extend_only) { fe_free(xnnnn_s); fe_free(xnnnn_s_inv); fe_free(s0); fe_free(s1); return t; }
     /* z0_s1, z1_s0 (:384-405) */
     t->z0_s1 = fe_alloc(hn); t->z1_s0 = fe_alloc(hn);
     if (n > 2) {

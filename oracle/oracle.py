@@ -31,6 +31,7 @@ class _Field:
             build()
         self.lib = ctypes.CDLL(path)
         self._sig("build_fftree", ctypes.c_void_p, [ctypes.c_uint, ctypes.c_int])
+        self._sig("build_extend_tree", ctypes.c_void_p, [ctypes.c_uint])
         self._sig("free_tree", None, [ctypes.c_void_p])
         self._sig("tree_size", ctypes.c_size_t, [ctypes.c_void_p])
         self._sig("table", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)])
@@ -97,6 +98,13 @@ class _Field:
         """FftreeField::build_fftree (src/lib.rs:14-16): None if n exceeds the curve's 2-adicity."""
         assert n > 0 and n & (n - 1) == 0, "n must be a power of two"  # src/lib.rs:41
         h = self._build_fftree(n.bit_length() - 1, int(check_chain))
+        return OracleFFTree(self, h) if h else None
+
+    def build_extend_tree(self, e):
+        """TEST INFRASTRUCTURE: T_2e with only what FFTree::extend of e evaluations reads (f layers + matrices, src/fftree.rs:72-126,
+        341-363) — for configs[3], whose full 2^23 chain would take a quarter of an hour.  Only `.extend` of exactly e values works."""
+        assert e > 0 and e & (e - 1) == 0
+        h = self._build_extend_tree(e.bit_length())            # log2(2e)
         return OracleFFTree(self, h) if h else None
 
     def _binop(self, fn, a, b):

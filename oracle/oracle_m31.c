@@ -116,7 +116,7 @@ static ecpoint velu2_map(const ratmap* r, const fe hnum[3], const fe hden[3], ec
 }
 
 /* m31::Fp::build_fftree (src/lib.rs:199-214) -> build_ec_fftree (src/ec.rs:498-554) */
-void* ORA(build_fftree)(unsigned log_n, int check_chain) {
+static void* build_impl(unsigned log_n, int check_chain, int extend_only) {
     (void)check_chain; /* the two-adicity test is part of the algorithm here (src/ec.rs:534) */
     swcurve curve = {1, 0};
     ecpoint offset = {1048755163u, 279503108u, 0}, gen = {1273083559u, 804329170u, 0};
@@ -144,10 +144,16 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
     size_t n = (size_t)1 << log_n;
     fe* leaves = fe_alloc(n);
     ec_leaves(&w, offset, gen, leaves, n);                     /* :546-551 */
+    ora_extend_only = extend_only;
     fftree* t = tree_new(leaves, n, maps, (int)log_n);
+    ora_extend_only = 0;
     free(maps); fe_free(leaves);
     return t;
 }
+void* ORA(build_fftree)(unsigned log_n, int check_chain) { return build_impl(log_n, check_chain, 0); }
+/* TEST INFRASTRUCTURE: the tree with 2^log_n leaves holding only what FFTree::extend of 2^(log_n - 1) evaluations reads (fftree_generic.h,
+ * ora_extend_only); every other call on it fails or crashes — the Python wrapper exposes extend only */
+void* ORA(build_extend_tree)(unsigned log_n) { return build_impl(log_n, 0, 1); }
 /* leaves idx[0..k) of the n = 2^log_n point set of build_fftree above (src/lib.rs:201-206, src/ec.rs:518-521, 545-551) */
 int ORA(leaves_at)(unsigned log_n, const uint64_t* idx, size_t k, void* out) {
     swcurve curve = {1, 0};

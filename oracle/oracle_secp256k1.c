@@ -52,7 +52,7 @@ static fe fe_from_dec(const char* s) {
 
 /* Fp::build_fftree (src/lib.rs:40-84). check_chain != 0 also runs the two-adicity assertion of
  * find_isogeny_chain (src/ec.rs:184), which costs O(log^2 n) point doublings. */
-void* ORA(build_fftree)(unsigned log_n, int check_chain) {
+static void* build_impl(unsigned log_n, int check_chain, int extend_only) {
 
     goodcurve curve;
     if (!goodcurve_new_odd(
@@ -86,10 +86,16 @@ void* ORA(build_fftree)(unsigned log_n, int check_chain) {
         }
         cur = next;
     }
+    ora_extend_only = extend_only;
     fftree* t = tree_new(leaves, n, maps, (int)log_n);
+    ora_extend_only = 0;
     free(maps); fe_free(leaves);
     return t;
 }
+void* ORA(build_fftree)(unsigned log_n, int check_chain) { return build_impl(log_n, check_chain, 0); }
+/* TEST INFRASTRUCTURE: the tree with 2^log_n leaves holding only what FFTree::extend of 2^(log_n - 1) evaluations reads (fftree_generic.h,
+ * ora_extend_only); every other call on it fails or crashes — the Python wrapper exposes extend only */
+void* ORA(build_extend_tree)(unsigned log_n) { return build_impl(log_n, 0, 1); }
 /* leaves idx[0..k) of the n = 2^log_n point set of build_fftree above (same constants, src/lib.rs:45-78); 0 on success */
 int ORA(leaves_at)(unsigned log_n, const uint64_t* idx, size_t k, void* out) {
     goodcurve curve;

@@ -65,6 +65,36 @@ class _OracleHeadline:
         return self.res
 
 
+class _OracleExtend22:
+    """BASELINE.json configs[3] on the oracle: EXTEND of e = 2^22 secp256k1 evaluations, both directions, on T_2^23 — built with only what
+    extend_impl reads (oracle.build_extend_tree: f layers + matrices; the whole 2^23 chain would take a quarter of an hour), on a
+    background host thread like the trees above."""
+    LOG_E = 22
+
+    def __init__(self, oracle_mod):
+        import threading
+        self.o, self.F = oracle_mod, oracle_mod.field("secp256k1")
+        self.res, self.err = {}, []
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def input(self):
+        return rand_elems(self.F, 1 << self.LOG_E, 0x5EED0722)
+
+    def _run(self):
+        try:
+            xt = self.F.build_extend_tree(1 << self.LOG_E)
+            h = self.input()
+            self.res = dict(ext_s1=xt.extend(h, self.o.S1), ext_s0=xt.extend(h, self.o.S0))
+        except Exception as e:  # pragma: no cover
+            self.err.append(e)
+
+    def get(self):
+        self.th.join()
+        assert not self.err, self.err
+        return self.res
+
+
 _oracle_headline = {}
 
 
@@ -73,6 +103,7 @@ def oracle_headline(oracle_mod, gpu):
     if not _oracle_headline:
         _oracle_headline["secp256k1"] = _OracleHeadline(oracle_mod, "secp256k1", 20, (20, 19))
         _oracle_headline["m31"] = _OracleHeadline(oracle_mod, "m31", 24, (24, 22))
+        _oracle_headline["extend22"] = _OracleExtend22(oracle_mod)
     return _oracle_headline
 
 
@@ -413,6 +444,17 @@ def test_config4_extend_2e22(gpu, gpu_tree, oracle_mod):
     s0, s1 = ev[0::2].copy(), ev[1::2].copy()
     assert np.array_equal(t.extend(s0, gpu.Moiety.S1), s1)
     assert np.array_equal(t.extend(s1, gpu.Moiety.S0), s0)
+
+
+def test_config4_extend_2e22_vs_oracle(gpu, gpu_tree, oracle_headline):
+    """round 5: BASELINE.json configs[3] — EXTEND of e = 2^22 secp256k1 evaluations on T_2^23 — against the CPU oracle ELEMENT FOR ELEMENT,
+    both directions, arbitrary input.  (test_config4_extend_2e22 above keeps the Horner leaves and the S0 <-> S1 property.)"""
+    job = oracle_headline["extend22"]
+    want = job.get()
+    h = job.input()
+    t = gpu_tree("secp256k1", 2 << job.LOG_E)
+    assert np.array_equal(t.extend(h, gpu.Moiety.S1), want["ext_s1"])
+    assert np.array_equal(t.extend(h, gpu.Moiety.S0), want["ext_s0"])
 
 
 def test_unaligned_device_buffers_take_the_scalar_paths(gpu, gpu_tree):

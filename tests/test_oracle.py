@@ -29,6 +29,19 @@ def test_leaves_at_equals_the_golden_leaves_and_the_subtree_rule(oracle_tree, or
     assert np.array_equal(F.leaves_at(1 << 22, 2 * idx), F.leaves_at(1 << 21, idx))
 
 
+@pytest.mark.parametrize("field", FIELDS)
+def test_extend_only_tree_extends_like_the_full_tree(oracle_tree, oracle_mod, field):
+    """oracle.build_extend_tree (f layers + matrices of ONE tree: what extend_impl reads, src/fftree.rs:72-126, 341-363 — used for
+    BASELINE configs[3], whose whole 2^23 chain would take a quarter of an hour) gives the EXTEND of the full tree, both directions"""
+    F, full = oracle_tree(field, 4096)
+    xt = F.build_extend_tree(2048)
+    g = load_golden(field, 4096)
+    s0, s1 = std_to_field(F, g["extend_s0"]), std_to_field(F, g["extend_s1"])
+    assert np.array_equal(xt.extend(s0, oracle_mod.S1), s1) and np.array_equal(xt.extend(s1, oracle_mod.S0), s0)
+    x = std_to_field(F, g["enter_evals"])[:2048]
+    assert np.array_equal(xt.extend(x, oracle_mod.S1), full.extend(x, oracle_mod.S1))
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_secp_rational_maps(oracle_tree, n):
     F, t = oracle_tree("secp256k1", n)
