@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
     ap.add_argument("--split-log-n", type=int, default=20, help="--gpus N > 1: size of the ONE ENTER+EXIT split over the ranks reported under `split` (0 = skip)")
     ap.add_argument("--split-log-e", type=int, default=22, help="--gpus N > 1: size of the ONE EXTEND split over the ranks reported under `split` (0 = skip)")
+    ap.add_argument("--stripe-min-gain", type=int, default=None, help="--gpus N > 1: ecfft_comm_set_link_striping threshold in bytes for the split part (default: the library's 4 MiB; 0 = always when it helps; -1 = never)")
     ap.add_argument("--split-exit", default="auto", choices=["auto", "gather", "shard"],
                     help="--gpus N > 1: form of the split EXIT — gather: full (replicated) context, ONE all-gather, top levels redundant; shard: "
                          "EXIT-shard context, split top levels; auto: gather up to n = 2^21, shard above")
@@ -169,6 +170,8 @@ def main():
 
     import torch
     import ecfft_amd
+    global _STRIPE_MIN_GAIN
+    _STRIPE_MIN_GAIN = args.stripe_min_gain
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -439,6 +442,7 @@ def main():
 
 
 _LIVE_COMMS = []          # communicators of the split part: the watchdog aborts them when the part is stuck
+_STRIPE_MIN_GAIN = None   # --stripe-min-gain
 
 
 def _make_comm(D, dist, world):
@@ -454,6 +458,8 @@ def _make_comm(D, dist, world):
         except Exception:      # already bound by an earlier communicator of this process
             pass
     c = D.Comm.rccl() if transport == "rccl" else D.Comm.callback()
+    if _STRIPE_MIN_GAIN is not None:
+        c.set_link_striping((1 << 64) - 1 if _STRIPE_MIN_GAIN < 0 else _STRIPE_MIN_GAIN)
     _LIVE_COMMS.append(c)
     return c
 

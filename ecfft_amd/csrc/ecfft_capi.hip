@@ -951,6 +951,11 @@ int ecfft_comm_get_unique_id(void* id_out) {
     memcpy(id_out, id.internal, ECFFT_COMM_ID_BYTES);
     return ECFFT_OK;
 }
+int ecfft_comm_set_link_striping(ecfft_comm* comm, size_t min_gain_bytes) {
+    if (!comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    comm->t->stripe_min_gain = min_gain_bytes;
+    return ECFFT_OK;
+}
 int ecfft_comm_set_rccl_library(const char* path) {
     return RcclApi::set_library(path) ? ECFFT_OK : ECFFT_ERR_BAD_ARG;
 }

@@ -83,7 +83,7 @@ public:
     size_t stripe_min_gain = (size_t)4 << 20;
     bool exchange_striped(const PatternFn& pat, const P2P* sends, int ns, const P2P* recvs, int nr, void* stage, size_t stage_bytes, hipStream_t s) {
         const int W = world, me = rank;
-        if (W < 4 || W > 64 || !stage) return exchange(sends, ns, recvs, nr, s);
+        if (W < 4 || W > 64 || !stage || stripe_min_gain == ~(size_t)0) return exchange(sends, ns, recvs, nr, s);      // ~0: striping switched off
         struct GM { int src, dst; size_t bytes, len; bool striped; int sidx, ridx; };      // sidx / ridx: index in my sends (src == me) / my receives (dst == me)
         std::vector<GM> gm; std::vector<MsgDesc> tmp;
         std::vector<size_t> D((size_t)W * W, 0), S1((size_t)W * W, 0), S2((size_t)W * W, 0);
@@ -116,7 +116,7 @@ public:
         // the staging bound is rank-independent on purpose (every rank must take the same decision): all relayed slices together, of
         // which a rank stages at most its 1/world-th ... world-th part
         for (const GM& g : gm) { any = any || g.striped; if (g.striped) need += g.len; }
-        if (!any || mD <= m1 + m2 || mD < m1 + m2 + stripe_min_gain || need > stage_bytes) return exchange(sends, ns, recvs, nr, s);
+        if (!any || mD <= m1 + m2 || mD - (m1 + m2) < stripe_min_gain || need > stage_bytes) return exchange(sends, ns, recvs, nr, s);
         // phase 1: slice k of every striped message to rank k (slice `dst` lands in place, slice `src` waits for phase 2); messages that
         // are not striped (small, self) whole.  Between one pair of ranks the messages match in the order given: both sides walk the
         // global list (source-major, each source's own order).

@@ -158,6 +158,12 @@ class Comm:
         fftree._check(L.ecfft_comm_init_projection(world, rank, device, float(delay_us), float(link_gbps), ctypes.byref(h)))
         return Comm(h)
 
+    def set_link_striping(self, min_gain_bytes):
+        """ecfft_comm_set_link_striping: threshold (bytes off the most loaded link) above which a pairwise exchange of a split ENTER / EXIT
+        is striped over all links of the mesh; 0 = whenever it helps, 2**64 - 1 = never.  The same value on every rank."""
+        from . import fftree
+        fftree._check(fftree.lib().ecfft_comm_set_link_striping(self._h, int(min_gain_bytes)))
+
     def abort(self):
         """ncclCommAbort (RCCL transports): unblocks exchanges in flight; later sharded calls on this communicator fail.  Returns
         False for a callback transport.  May be called from another thread than the blocked one."""

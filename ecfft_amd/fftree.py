@@ -31,7 +31,7 @@ EXPORTS = ["ecfft_elem_size", "ecfft_build_fftree", "ecfft_fftree_new", "ecfft_c
            "ecfft_mul_ceiling", "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_table_fma", "ecfft_enter_many", "ecfft_exit_many", "ecfft_mextend", "ecfft_redc", "ecfft_modular_reduce", "ecfft_vanish", "ecfft_degree",
            "ecfft_comm_get_unique_id", "ecfft_comm_init_rank", "ecfft_comm_init_callback", "ecfft_comm_destroy", "ecfft_comm_rank", "ecfft_comm_world",
            "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_extend_sharded", "ecfft_enter_sharded", "ecfft_exit_sharded", "ecfft_device_copy", "ecfft_shader_clock", "ecfft_device_alloc", "ecfft_device_free", "ecfft_device_sync", "ecfft_build_extend_shard", "ecfft_ctx_device_bytes", "ecfft_extend_sharded_layout", "ecfft_build_enter_shard", "ecfft_build_exit_shard", "ecfft_build_exit_shard_opts",
-           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_comm_abort", "ecfft_comm_set_rccl_library"]
+           "ecfft_fftree_serialize", "ecfft_fftree_deserialize", "ecfft_tree_rational_maps", "ecfft_ctx_trim", "ecfft_comm_abort", "ecfft_comm_set_rccl_library", "ecfft_comm_set_link_striping"]
 
 # include/ecfft_hip_hooks.h: only in a build with -DECFFT_TEST_HOOKS (tests/hooks/libecfft_hip_hooks.so), never in the shipped library
 HOOK_EXPORTS = ['ecfft_selftest_field', 'ecfft_selfcheck_pointwise_z', 'ecfft_test_fail_next_collective', 'ecfft_selftest_blk16', 'ecfft_selftest_blk16_small', 'ecfft_test_fail_build_rank', 'ecfft_comm_init_projection', 'ecfft_selftest_blk32', 'ecfft_ctx_low_map']
@@ -109,6 +109,7 @@ def _bind(L):
     L.ecfft_profile_read.restype, L.ecfft_profile_read.argtypes = ci, [vp, ci, ctypes.c_char_p, sz, ctypes.POINTER(ctypes.c_uint64),
                                                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.ecfft_comm_set_rccl_library.restype, L.ecfft_comm_set_rccl_library.argtypes = ci, [ctypes.c_char_p]
+    L.ecfft_comm_set_link_striping.restype, L.ecfft_comm_set_link_striping.argtypes = ci, [vp, sz]
     L.has_hooks = hasattr(L, "ecfft_selftest_field")
     if L.has_hooks:      # include/ecfft_hip_hooks.h (test builds only)
         L.ecfft_selftest_field.restype, L.ecfft_selftest_field.argtypes = ci, [ci, ci, vp, vp, vp, vp, sz, ci]

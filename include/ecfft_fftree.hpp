@@ -51,6 +51,8 @@ public:
     static void set_rccl_library(const char* path) { check(ecfft_comm_set_rccl_library(path)); }
     // ncclCommAbort: unblocks exchanges in flight (from another host thread); later sharded calls on this communicator fail
     bool abort() { return ecfft_comm_abort(c_) == ECFFT_OK; }
+    // threshold of the link striping of the big pairwise exchanges (ecfft_comm_set_link_striping); the same value on every rank
+    void set_link_striping(size_t min_gain_bytes) { check(ecfft_comm_set_link_striping(c_, min_gain_bytes)); }
     int rank() const { return ecfft_comm_rank(c_); }
     int world() const { return ecfft_comm_world(c_); }
     ecfft_comm* raw() const { return c_; }

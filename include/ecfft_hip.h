@@ -158,6 +158,12 @@ void ecfft_comm_destroy(ecfft_comm* comm);
  * call on this communicator return ECFFT_ERR_HIP; may be called from another host thread than the blocked one.  ECFFT_ERR_HIP for a
  * callback transport (the host owns its exchanges).  The librccl that is bound: ecfft_comm_set_rccl_library. */
 int ecfft_comm_abort(ecfft_comm* comm);
+/* Link striping of the big pairwise exchanges of a split ENTER / EXIT (round 5): a message travels as `world` slices, slice k via
+ * rank k, in two grouped exchanges, so that every link of the xGMI mesh carries 1/world of it per phase — applied to an exchange only
+ * when its most loaded link gets lighter by at least `min_gain_bytes` over both phases.  Default 4 MiB (>= 85 us at 48 GB/s against one
+ * more exchange latency); 0 = whenever striping moves fewer bytes over the most loaded link; SIZE_MAX = never.  Every rank of the
+ * communicator must use the same value (the decision is taken locally from the call's message pattern).  Returns ECFFT_OK. */
+int ecfft_comm_set_link_striping(ecfft_comm* comm, size_t min_gain_bytes);
 int ecfft_comm_rank(const ecfft_comm* comm);
 int ecfft_comm_world(const ecfft_comm* comm);
 /* communication time: while enabled every exchange is bracketed by HIP events on its stream; _read synchronises the device */

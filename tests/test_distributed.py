@@ -546,6 +546,39 @@ def test_link_striping_of_the_pairwise_exchanges_is_bit_exact(field, n, P, monke
 
 
 @pytest.mark.gpu
+def test_link_striping_threshold_through_the_abi():
+    """ecfft_comm_set_link_striping on the SHIPPED library (no environment switch): 0 stripes every exchange that striping makes
+    lighter, SIZE_MAX none, the default (4 MiB) none at this small size — same bits in all three, more grouped exchanges only with 0"""
+    import torch
+    import ecfft_amd
+    F = ecfft_amd.FIELDS["secp256k1"]
+    n, P = 1 << 15, 8
+    c = n // P
+    a = np.random.default_rng(5).integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+    x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = F.build_fftree(n).enter(x)
+    torch.cuda.synchronize()
+    counts = {}
+    for name, thr in (("default", None), ("always", 0), ("never", (1 << 64) - 1)):
+        got = {}
+
+        def body(rank, make_comm):
+            comm = make_comm()
+            if thr is not None:
+                comm.set_link_striping(thr)
+            esh = F.build_enter_shard(n, P, rank)
+            comm.stats(True)
+            got[rank] = esh.enter_sharded(comm, x[rank * c:(rank + 1) * c].clone(), n)
+            got[("nx", rank)] = comm.stats()["exchanges"]
+
+        _thread_ranks(P, body)
+        for r in range(P):
+            assert torch.equal(got[r], want[r * c:(r + 1) * c]), (name, r)
+        counts[name] = got[("nx", 0)]
+    assert counts["default"] == counts["never"] == 8 and counts["always"] > 8, counts
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("op", ["extend", "enter", "exit"])
 def test_local_failure_on_one_rank_fails_every_rank_instead_of_hanging(op, hooks_lib):
     """a sharded call whose local preparation fails on ONE rank (allocation failure; injected here with
