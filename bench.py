@@ -542,7 +542,7 @@ def extend_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev=
 
 def enter_exit_split(args, torch, dist, ecfft_amd, rank, local_rank, world, red_dev="cuda", log_n=None):
     """ONE ENTER followed by ONE EXIT of n = 2^log_n coefficients with the evaluation domain block-split over the ranks
-    (ecfft_amd/distributed.py: local low levels, split EXTENDs + table_fma + one all-to-all per top level).  Strong
+    (tests/split_model.py is the Python model of it: local low levels, split EXTENDs + table_fma + one all-to-all per top level).  Strong
     scaling.  Checked by EXIT(ENTER(c)) == c on every rank."""
     from ecfft_amd import distributed as D
     log_n = args.log_n if log_n is None else log_n

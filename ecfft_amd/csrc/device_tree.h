@@ -106,9 +106,6 @@ private:
          hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);               \
          if (prof_.on) prof_.end(stream); } while (0)
 
-#ifdef ECFFT_EXP_HALF_DELAY_US
-__global__ void k_exp_delay_us(unsigned long long ticks) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
-#endif
 template <class F>
 class DeviceChain {
 public:
@@ -1171,7 +1168,7 @@ public:
         // symmetric all-rank exchange, and a rank voting alone would pair its 4-byte messages with its peers' data messages
         // (ADVICE r04).  Should the impossible happen, the rank reports the error and its peers are released by the caller's
         // ecfft_comm_abort; the failure-injection hook only applies to shapes that still vote (it stays armed until one comes).
-        if (agreed_shapes_.count(key)) {
+        if (agreed_shapes_.count(key) && tr.voted()) {
             if (!local_ok) { fprintf(stderr, "ecfft: a pinned temporary of an agreed sharded call shape could not be taken\n"); temps_done(); }
             return local_ok;
         }
@@ -1383,11 +1380,26 @@ public:
             in_halves_ = true;
             enter_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
             in_halves_ = false;
+        } else if (batch_split(nt, count)) {
+            // round 6: a batch runs as two half-batches on two streams (whole polynomials: nothing to join but the end) — one half's
+            // load / store phases and launch fill / drain meet the other's multiplies, as in the two-halves schedule of one transform
+            hipStream_t s2 = sides_[0];
+            (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
+            in_halves_ = true;
+            enter_levels(in, out, n, count / 2, s, scratch_, 1, ln);
+            double w = tblw_; tblw_ = 0.0; enter_levels(in + nt / 2, out + nt / 2, n, count / 2, s2, scratch_ + 3 * (nt / 2), 1, ln); tblw_ = w;
+            in_halves_ = false;
+            (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
         } else {
             enter_levels(in, out, n, count, s, scratch_, 1, ln);
         }
         return true;
     }
+#ifndef ECFFT_BATCH_SPLIT
+#define ECFFT_BATCH_SPLIT 1
+#endif
+    // batched ENTER / EXIT as two concurrent half-batches: an even number of polynomials, each half at least 2^kSplitMinLog elements
+    bool batch_split(size_t nt, size_t count) const { return ECFFT_BATCH_SPLIT && count > 1 && (count & 1) == 0 && nside_ > 0 && (nt >> (kSplitMinLog + 1)) != 0; }
     // Concurrent halves, recursively: levels 1..L-1 never mix the two half-blocks, so they run as two independent ENTERs
     // of n/2 on two streams.  Their launches (each half as wide) interleave on the chip, so one half's load / store phases
     // overlap the other's compute; only the top level runs on the whole array.  Scratch: f(n) = n + 2 f(n/2), f = 3n at a leaf.
@@ -1484,6 +1496,14 @@ public:
             in_halves_ = true;
             exit_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
             in_halves_ = false;
+        } else if (batch_split(n, count)) {
+            hipStream_t s2 = sides_[0];
+            (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
+            in_halves_ = true;
+            exit_levels(in, out, n1, count / 2, s, scratch_, ln, 1);
+            double w = tblw_; tblw_ = 0.0; exit_levels(in + n / 2, out + n / 2, n1, count / 2, s2, scratch_ + 3 * (n / 2), ln, 1); tblw_ = w;
+            in_halves_ = false;
+            (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
         } else {
             exit_levels(in, out, n1, count, s, scratch_, ln, 1);
         }
@@ -1498,9 +1518,6 @@ public:
         E* Y = base; E* sA = base + n; E* sB = sA + scratch_need(n / 2, depth - 1);
         exit_levels(in, Y, n, 1, s, sA, ln, ln);
         (void)hipEventRecord(ev_fork_[me], s); (void)hipStreamWaitEvent(s2, ev_fork_[me], 0);
-#ifdef ECFFT_EXP_HALF_DELAY_US      // experiment: the second half-stream starts this much later (its k_exit_low then runs after the first one's)
-        hipLaunchKernelGGL(k_exp_delay_us, dim3(1), dim3(1), 0, s2, (unsigned long long)(ECFFT_EXP_HALF_DELAY_US) * 100ull);
-#endif
         exit_rec(Y, out, n / 2, s, sA, depth - 1, next_side);
         double w = tblw_; tblw_ = 0.0; exit_rec(Y + n / 2, out + n / 2, n / 2, s2, sB, depth - 1, next_side); tblw_ = w;
         (void)hipEventRecord(ev_join_[me], s2); (void)hipStreamWaitEvent(s, ev_join_[me], 0);
@@ -1670,7 +1687,7 @@ public:
 
     // out[i] = f(x[i], y[i], T[t_off + i*t_stride]) with T one of the reference's plain tables of T_m (data x
     // plain table needs no Montgomery correction).  mode 0: x*T   1: x*T + y   2: y - x*T   3: (y - x)*T.
-    // The pointwise steps of the multi-GPU ENTER / EXIT (ecfft_amd/distributed.py) are built from this.
+    // The pointwise steps of the multi-GPU ENTER / EXIT are built from this (Python model: tests/split_model.py).
     bool table_fma(E* out, const E* x, const E* y, size_t cnt, unsigned log_m, int which, size_t t_off, size_t t_stride, int mode, hipStream_t s) const {
         const Tree& T = trees_[log_m];
         const E* tbl = nullptr; size_t len = 0;

@@ -953,6 +953,7 @@ int ecfft_comm_get_unique_id(void* id_out) {
 }
 int ecfft_comm_set_link_striping(ecfft_comm* comm, size_t min_gain_bytes) {
     if (!comm || !comm->t) return ECFFT_ERR_BAD_ARG;
+    if (comm->t->used()) return ECFFT_ERR_BAD_ARG;      // frozen once the communicator has carried an exchange: the ranks agree on it in their first vote
     comm->t->stripe_min_gain = min_gain_bytes;
     return ECFFT_OK;
 }

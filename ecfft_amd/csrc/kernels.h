@@ -24,6 +24,26 @@ constexpr int kBlock = 256;
 // Workgroup barrier that publishes LDS writes only: __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)),
 // which would turn every table request issued ahead of the barrier into a wait AT the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Round 6: sweeps whose pairs stay inside one wave's own 128-element span (one pair per thread, pair distance <= 64: the wave that
+// wrote an element is the only one that reads it next) need no WORKGROUP barrier between them.  LDS operations of one wave execute
+// in issue order, so a wavefront-scope fence (no instruction; it only stops the compiler from moving LDS accesses across it) is all
+// the ordering there is to ask for.  ECFFT_WAVE_LOCAL: 0 = workgroup barrier everywhere (rounds 1-5), 1 = wavefront fence,
+// 2 = s_waitcnt lgkmcnt(0) without the s_barrier (A/B forms; profiles/r06/wave_local_ab.txt).
+#ifndef ECFFT_WAVE_LOCAL
+#define ECFFT_WAVE_LOCAL 1
+#endif
+__device__ __forceinline__ void wave_local_sync() {
+#if ECFFT_WAVE_LOCAL == 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif ECFFT_WAVE_LOCAL == 1
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+#else
+    lds_barrier();
+#endif
+}
+// pair distance 2^lh of a one-pair-per-thread sweep (idx = ((tid >> lh) << (lh + 1)) + (tid & (h - 1))): wave-local iff h <= 64
+__device__ __forceinline__ constexpr bool wave_local_lh(int lh) { return ECFFT_WAVE_LOCAL != 0 && lh <= 6; }
 #ifndef ECFFT_RADIX_LDSBAR
 #define ECFFT_RADIX_LDSBAR 1                 // 4-byte engine: the barrier behind the early table requests is LDS-only
 #endif
@@ -578,9 +598,11 @@ __device__ __forceinline__ void lds_extend_fast(typename F::elem* a, const typen
 // Row-kernel sweeps of a 32-byte field, one pair per thread (tile = 2 * BLK elements), with the two table constants of the NEXT
 // sweep requested before the barrier that ends the current one (see col_stages_pipe).  Pair distances 2^lh_from .. 2^lh_to
 // (downwards for DEC, upwards otherwise), table entry e - 2h + (pair index mod h).  Ends with a barrier.
+// lh_after: pair-distance log of a one-pair-per-thread consumer that follows the last sweep (then the closing barrier is relaxed
+// like the ones between wave-local sweeps), or 99 = the consumer reads other waves' elements.
 template <class F, bool DEC>
 __device__ __forceinline__ void row_stages_pipe(typename F::elem* tile, const typename F::telem* __restrict__ ta, const typename F::telem* __restrict__ tb,
-                                                uint32_t e, int lh_from, int lh_to, uint32_t tid) {
+                                                uint32_t e, int lh_from, int lh_to, uint32_t tid, int lh_after = 99) {
     using E = typename F::elem;
     using TE = typename F::telem;
     if (DEC ? lh_from < lh_to : lh_from > lh_to) return;
@@ -599,7 +621,8 @@ __device__ __forceinline__ void row_stages_pipe(typename F::elem* tile, const ty
         if (DEC) { const E q1 = F::tmul(t1, F::sub(b, a)); tile[lo] = F::tmul_add(t0, q1, a); tile[up] = q1; }
         else { const E o0 = F::tmul_add(t0, b, a), o1 = F::tmul_add(t1, b, a); tile[lo] = o0; tile[up] = o1; }
         if (lh != lh_to) { geom(lh + (DEC ? -1 : 1), idx, ti); na = ldt(ta, ti); nb = ldt(tb, ti); }
-        lds_barrier();
+        const int nxt = lh != lh_to ? lh + (DEC ? -1 : 1) : lh_after;
+        if (wave_local_lh(lh) && wave_local_lh(nxt)) wave_local_sync(); else lds_barrier();
     }
 }
 
@@ -662,7 +685,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     bool pipe = false;                                                  // one pair per thread: constants one sweep ahead
     if constexpr (sizeof(E) == 32 && ECFFT_ROW_PIPE) pipe = npairs == (uint32_t)kBlockRow && (e >> 31) == 0;
     if (pipe) {
-        if constexpr (sizeof(E) == 32) row_stages_pipe<F, true>(tile, np0, dinv, (uint32_t)e, (int)(log_e - k_first) - 1, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), tid);
+        if constexpr (sizeof(E) == 32) row_stages_pipe<F, true>(tile, np0, dinv, (uint32_t)e, (int)(log_e - k_first) - 1, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), tid, fuse16 ? 4 : 99);
     } else
     for (uint32_t k = k_first; k < k_dec_end - (fuse16 ? 1u : 0u); ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
@@ -680,7 +703,8 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                 __builtin_amdgcn_sched_barrier(0);
                 pre = Blk16::prefetch(blkA, tid);                        // after the multiplies (they need the registers), before the barriers
                 __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                                         // operand form permutes chunks across threads' elements
+                // operand form permutes chunks across threads' elements — inside 8-element groups (Blk16::phys), i.e. inside the wave's span
+                if (ECFFT_WAVE_LOCAL) wave_local_sync(); else __syncthreads();
                 Blk16::store_operand(tile, idx, q0); Blk16::store_operand(tile, idx + 16, q1);
                 __syncthreads();
             } else {
@@ -699,9 +723,11 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                 const uint32_t i = tid & 15u, idx = ((tid >> 4) << 5) + i;
                 const E a = Blk16::load_swizzled(tile, idx), b = Blk16::load_swizzled(tile, idx + 16);
                 const E o0 = F::tmul_add(ldt(p0 + (e - 32), i), b, a), o1 = F::tmul_add(ldt(p1 + (e - 32), i), b, a);
-                __syncthreads();
+                // the swizzled positions read above and the plain ones written below lie in the wave's own span; so do the pairs of the
+                // recombine sweep at distance 32 that follows in the pipelined form
+                if (ECFFT_WAVE_LOCAL) wave_local_sync(); else __syncthreads();
                 tile[idx] = o0; tile[idx + 16] = o1;
-                __syncthreads();
+                if (ECFFT_WAVE_LOCAL && pipe && k_first + 1 < k_dec_end) wave_local_sync(); else __syncthreads();
             } else {
                 Blk16::from_swizzled<kBlockRow>(tile, T, tid);
             }
@@ -928,7 +954,10 @@ __device__ __forceinline__ void col_stages_pipe(typename F::elem* tile, const ty
             else { const E o0 = F::tmul_add(ldt(ta, i2), b, a), o1 = F::tmul_add(ldt(tb, i2), b, a); tile[l2] = o0; tile[u2] = o1; }
         }
         if (st + 1 < R) { geom(st + 1, tid, lo, up, ti); na = ldt(ta, ti); nb = ldt(tb, ti); }
-        lds_barrier();
+        // pairs g in [64 q, 64 q + 64) of a stage with element distance (C << sft) <= 64 fill one aligned span of 128 elements, the same
+        // span for every such stage: between two of them only the wave's own LDS traffic has to be ordered (wave_local_sync)
+        const uint32_t sft = DEC ? R - 1 - st : st, sft_n = DEC ? sft - 1 : sft + 1;
+        if (st + 1 < R && wave_local_lh((int)(sft + log_c)) && wave_local_lh((int)(sft_n + log_c))) wave_local_sync(); else lds_barrier();
     }
 }
 
@@ -1546,10 +1575,13 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
     bool mfma = false;
     if constexpr (sizeof(E) == 32 && BLK == 512) mfma = bA != nullptr && (len & 1023u) == 0;
     const uint32_t k_dec_end = mfma ? log_e - 4 : k_inner;
+    // one-pair-per-thread sweeps (32-byte fields, at least one pair per thread): the sweeps at pair distance <= 64 stay inside the
+    // wave's own span, and so does the merged innermost stage — no workgroup barrier between them (wave_local_sync)
+    const bool wl = sizeof(E) == 32 && 2 * npairs > (uint32_t)BLK;
     for (uint32_t k = 0; k < k_dec_end; ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, true, BLK>(a, T.np0[srcpar] + (e - 2 * (size_t)h), T.dinv[srcpar] + (e - 2 * (size_t)h), lh, npairs, tid, T.c0t[srcpar] + (e - 2 * (size_t)h));
-        __syncthreads();
+        if (wl && wave_local_lh((int)lh) && (k + 1 < k_dec_end || !mfma)) wave_local_sync(); else __syncthreads();
     }
     if constexpr (sizeof(E) == 32 && BLK == 512) {
         if (mfma) {
@@ -1572,12 +1604,12 @@ __device__ __forceinline__ void lds_extend_core(typename F::elem* a, uint32_t le
             a[2 * g] = F::tmul_add(c0, d, x);
             a[2 * g + 1] = F::tmul_add(c1, d, x);
         }
-        __syncthreads();
+        if (wl && ECFFT_WAVE_LOCAL && k_dec_end > 0) wave_local_sync(); else __syncthreads();
     }
     for (uint32_t k = k_dec_end; k-- > 0;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
         stage_sweep<F, false, BLK>(a, T.p0[tgt] + (e - 2 * (size_t)h), T.p1[tgt] + (e - 2 * (size_t)h), lh, npairs, tid);
-        __syncthreads();
+        if (wl && k > 0 && wave_local_lh((int)lh + 1)) wave_local_sync(); else __syncthreads();
     }
 }
 

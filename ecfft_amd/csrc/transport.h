@@ -38,6 +38,7 @@ public:
     bool exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) {
         hipEvent_t a = nullptr, b = nullptr;
         if (stats_on_) { a = next_event(); b = next_event(); (void)hipEventRecord(a, s); }
+        carried_ = true;
         bool ok = do_exchange(sends, ns, recvs, nr, s);
         if (stats_on_) { (void)hipEventRecord(b, s); pairs_.push_back({a, b}); }
         ++calls_;
@@ -49,22 +50,40 @@ public:
     // its peers blocked in the exchanges that follow — every rank votes BEFORE the first exchange and all of them back out
     // together.  Synchronous; used once per (context, call shape) and between the phases of the collective EXIT-shard build.
     bool vote(bool ok, hipStream_t s) {
+        voted_ = true;
         if (world <= 1) return ok;
-        if (!vote_dev_ && hipMalloc(&vote_dev_, (size_t)(world + 1) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); vote_dev_ = nullptr; }
-        if (!vote_dev_) { fprintf(stderr, "ecfft: no device memory for the agreement buffer\n"); return false; }   // 4*(world+1) bytes: unreachable in practice
-        int mine = ok ? 1 : 0;
-        if (hipMemcpyAsync(vote_dev_ + world, &mine, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+        carried_ = true;
+        // three ints per rank: the vote and the rank's link-striping threshold ("the same value on every rank" was an
+        // unchecked contract, and exchange_striped decides locally — ranks that disagree would pair differently sized messages)
+        constexpr int kW = 3;
+        if (!vote_dev_ && hipMalloc(&vote_dev_, (size_t)(world + 1) * kW * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); vote_dev_ = nullptr; }
+        if (!vote_dev_) { fprintf(stderr, "ecfft: no device memory for the agreement buffer\n"); return false; }   // 12*(world+1) bytes: unreachable in practice
+        const unsigned long long g = (unsigned long long)stripe_min_gain;
+        int mine[kW] = {ok ? 1 : 0, (int)(unsigned)(g & 0xFFFFFFFFull), (int)(unsigned)(g >> 32)};
+        if (hipMemcpyAsync(vote_dev_ + world * kW, mine, sizeof(mine), hipMemcpyHostToDevice, s) != hipSuccess) return false;
         if (hipStreamSynchronize(s) != hipSuccess) return false;
         std::vector<P2P> snd, rcv;
-        for (int p = 0; p < world; ++p) if (p != rank) { snd.push_back({p, vote_dev_ + world, sizeof(int)}); rcv.push_back({p, vote_dev_ + p, sizeof(int)}); }
+        for (int p = 0; p < world; ++p) if (p != rank) { snd.push_back({p, vote_dev_ + world * kW, sizeof(mine)}); rcv.push_back({p, vote_dev_ + p * kW, sizeof(mine)}); }
         if (!do_exchange(snd.data(), (int)snd.size(), rcv.data(), (int)rcv.size(), s)) return false;
-        std::vector<int> all((size_t)world + 1, 0);
+        std::vector<int> all((size_t)(world + 1) * kW, 0);
         if (hipStreamSynchronize(s) != hipSuccess) return false;
-        if (hipMemcpy(all.data(), vote_dev_, (size_t)(world + 1) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(all.data(), vote_dev_, all.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
         bool every = ok;
-        for (int p = 0; p < world; ++p) if (p != rank && all[(size_t)p] != 1) every = false;
+        for (int p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            if (all[(size_t)p * kW] != 1) every = false;
+            if (all[(size_t)p * kW + 1] != mine[1] || all[(size_t)p * kW + 2] != mine[2]) {
+                fprintf(stderr, "ecfft: rank %d and rank %d disagree on the link-striping threshold (ecfft_comm_set_link_striping: the same value on every rank)\n", rank, p);
+                every = false;
+            }
+        }
         return every;
     }
+    // true once the communicator has carried an exchange or a vote: its link-striping threshold is frozen from then on
+    bool used() const { return carried_; }
+    // false until the ranks of this communicator have voted once (and thereby compared their striping thresholds): the first sharded
+    // call on a communicator votes even when the context already knows the call's shape from another communicator
+    bool voted() const { return voted_; }
     // ---- link striping (round 5) --------------------------------------------------------------------------------------------
     // xGMI is a full mesh of point-to-point links (7 per GPU).  The big exchanges of a split ENTER / EXIT are PAIRWISE — a rank hands
     // its whole share to one or two peers (the level's re-distribution, the pair level) — so one or two links carry 8 .. 16 MiB
@@ -76,32 +95,38 @@ public:
     // they are the relays — which the SPMD call sequence of the sharded transforms guarantees; the global message pattern is a pure
     // function of the rank (`pat(q)` = the (destination, bytes) list rank q sends, in order), evaluated locally for every q, so no
     // pattern is ever communicated.  An exchange is striped only when the most loaded link gets lighter by `stripe_min_gain` bytes
-    // over both phases (default 4 MiB: >= 85 us at 48 GB/s against one more ~25 us exchange latency — the 4 MiB messages of an
-    // n = 2^20 split stay direct, the 8 - 16 MiB ones of n = 2^22 are striped); everything else goes through unchanged.
+    // over both phases.  OFF by default (round 6): striping has run bit-exactly over the callback transport, the RCCL
+    // stand-in and host threads, but never on xGMI — it doubles the bytes a rank injects (relay traffic), adds one exchange and issues
+    // ~2 (W - 1) sends and receives per group, so until an 8-GPU A/B exists a host opts in with ecfft_comm_set_link_striping (4 MiB is
+    // the threshold the projection suggests: >= 85 us at 48 GB/s against one more exchange; bench.py --stripe-min-gain).
     struct MsgDesc { int dst; size_t bytes; };
     typedef std::function<void(int, std::vector<MsgDesc>&)> PatternFn;
-    size_t stripe_min_gain = (size_t)4 << 20;
+    size_t stripe_min_gain = ~(size_t)0;
     bool exchange_striped(const PatternFn& pat, const P2P* sends, int ns, const P2P* recvs, int nr, void* stage, size_t stage_bytes, hipStream_t s) {
         const int W = world, me = rank;
         if (W < 4 || W > 64 || !stage || stripe_min_gain == ~(size_t)0) return exchange(sends, ns, recvs, nr, s);      // ~0: striping switched off
+        // A mismatch between the pattern and what this rank really sends / receives is a bug in the caller's pattern function.  It is an
+        // ERROR, not a fall-back to the plain exchange: the peers evaluate the same pattern and go on with the two-phase
+        // exchange, so a rank that quietly sends its messages whole would pair them with their slices.
+        auto bad = [&](const char* what) { fprintf(stderr, "ecfft: striped exchange on rank %d: %s\n", me, what); return false; };
         struct GM { int src, dst; size_t bytes, len; bool striped; int sidx, ridx; };      // sidx / ridx: index in my sends (src == me) / my receives (dst == me)
         std::vector<GM> gm; std::vector<MsgDesc> tmp;
         std::vector<size_t> D((size_t)W * W, 0), S1((size_t)W * W, 0), S2((size_t)W * W, 0);
         for (int q = 0; q < W; ++q) {
             tmp.clear(); pat(q, tmp);
             if (q == me) {                                                            // the pattern must describe what this rank really sends
-                if ((int)tmp.size() != ns) return exchange(sends, ns, recvs, nr, s);
-                for (int i = 0; i < ns; ++i) if (tmp[(size_t)i].dst != sends[i].peer || tmp[(size_t)i].bytes != sends[i].bytes) return exchange(sends, ns, recvs, nr, s);
+                if ((int)tmp.size() != ns) return bad("the message pattern lists another number of sends than the call makes");
+                for (int i = 0; i < ns; ++i) if (tmp[(size_t)i].dst != sends[i].peer || tmp[(size_t)i].bytes != sends[i].bytes) return bad("the message pattern disagrees with a send of the call (peer or size)");
             }
             int seen = 0;                                                             // messages of q to me so far
             for (size_t i = 0; i < tmp.size(); ++i) {
                 const int d = tmp[i].dst; const size_t b = tmp[i].bytes;
-                if (d < 0 || d >= W) return exchange(sends, ns, recvs, nr, s);
+                if (d < 0 || d >= W) return bad("the message pattern names a rank outside the communicator");
                 GM g{q, d, b, b / (size_t)W, q != d && b >= ((size_t)64 << 10) && b % ((size_t)16 * W) == 0, q == me ? (int)i : -1, -1};
                 if (d == me) {                                                        // the t-th message q sends me = my t-th receive from q
                     const int t = seen++; int c = 0;
                     for (int j = 0; j < nr; ++j) if (recvs[j].peer == q && c++ == t) { g.ridx = j; break; }
-                    if (g.ridx < 0 || recvs[g.ridx].bytes != b) return exchange(sends, ns, recvs, nr, s);
+                    if (g.ridx < 0 || recvs[g.ridx].bytes != b) return bad("the message pattern disagrees with a receive of the call (missing or of another size)");
                 }
                 gm.push_back(g);
                 if (q != d) D[(size_t)q * W + d] += b;
@@ -109,7 +134,7 @@ public:
                 else if (q != d) S1[(size_t)q * W + d] += b;
             }
         }
-        { int mine = 0; for (const GM& g : gm) mine += g.dst == me; if (mine != nr) return exchange(sends, ns, recvs, nr, s); }
+        { int mine = 0; for (const GM& g : gm) mine += g.dst == me; if (mine != nr) return bad("the call posts receives the message pattern does not contain"); }
         size_t mD = 0, m1 = 0, m2 = 0, need = 0;
         for (size_t i = 0; i < D.size(); ++i) { if (D[i] > mD) mD = D[i]; if (S1[i] > m1) m1 = S1[i]; if (S2[i] > m2) m2 = S2[i]; }
         bool any = false;
@@ -167,6 +192,7 @@ private:
     std::vector<hipEvent_t> ev_; size_t used_ = 0; std::vector<Pair> pairs_;
     bool stats_on_ = false; uint64_t calls_ = 0; double bytes_ = 0;
     int* vote_dev_ = nullptr;
+    bool carried_ = false, voted_ = false;
 };
 
 // ---- RCCL, bound at run time -------------------------------------------------------------------------------------------
@@ -245,7 +271,12 @@ public:
         // that ends within microseconds on RCCL (what BLOCKS is the stream behind it), so wait for it to leave before the
         // communicator is freed — bounded (0.2 s), because a transport library whose receive blocks on the HOST (the tests' stand-in)
         // is only released by the abort itself
-        for (int spin = 0; in_enqueue_.load(std::memory_order_acquire) != 0 && spin < 2000; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        // (Dekker-style handshake with do_exchange: store comm_ / load in_enqueue_ here, increment in_enqueue_ / load comm_ there —
+        // every one of the four accesses is sequentially consistent, which is what makes "either I see the section or it sees no
+        // communicator" hold in the C++ memory model.)  If the 0.2 s expire — a transport whose enqueue itself blocks on the host —
+        // the communicator is aborted under the section all the same: that is the documented way to release it, and the section's
+        // remaining calls then fail inside the library instead of hanging.
+        for (int spin = 0; in_enqueue_.load(std::memory_order_seq_cst) != 0 && spin < 2000; ++spin) std::this_thread::sleep_for(std::chrono::microseconds(100));
         return api.CommAbort(c) == 0;
     }
     bool init(const void* id128, int world_, int rank_, int device_) {
@@ -262,7 +293,7 @@ public:
 protected:
     bool do_exchange(const P2P* sends, int ns, const P2P* recvs, int nr, hipStream_t s) override {
         RcclApi& api = RcclApi::get();
-        struct Enq { std::atomic<int>& n; explicit Enq(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_acq_rel); } ~Enq() { n.fetch_sub(1, std::memory_order_acq_rel); } } enq(in_enqueue_);
+        struct Enq { std::atomic<int>& n; explicit Enq(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_seq_cst); } ~Enq() { n.fetch_sub(1, std::memory_order_seq_cst); } } enq(in_enqueue_);
         RcclApi::Comm c = comm_.load();                   // read INSIDE the section: abort() either sees the section or this sees no communicator
         if (aborted_.load() || !c) return false;
         const int kChar = 0;                              // ncclChar / ncclInt8

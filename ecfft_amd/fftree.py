@@ -323,7 +323,10 @@ class FFTree:
 
     def __init__(self, field, handle, device, maps=None):
         self.field, self._h, self.device = field, handle, device
-        self.n = lib().ecfft_tree_size(handle)
+        # the library that created the handle serves every later call on it, __del__ included: with use_library /
+        # use_hooks_library a handle can outlive the with-block it was made in, and lib() would then name another .so instance
+        self._L = lib()
+        self.n = self._L.ecfft_tree_size(handle)
         self._from_build = maps is None          # build_fftree: the maps are those of build_points(n)
         if maps is not None:
             self._num, self._den = maps
@@ -331,16 +334,16 @@ class FFTree:
     @property
     def device_bytes(self):
         """HBM the context holds between calls (tables + transform scratch + pooled temporaries)"""
-        return lib().ecfft_ctx_device_bytes(self._h)
+        return self._L.ecfft_ctx_device_bytes(self._h)
 
     def trim(self):
         """return the pooled temporaries of the algorithm wrappers to the device (ecfft_ctx_trim)"""
-        _check(lib().ecfft_ctx_trim(self._h))
+        _check(self._L.ecfft_ctx_trim(self._h))
 
     def __del__(self):
         try:
             if self._h:
-                lib().ecfft_ctx_destroy(self._h)
+                self._L.ecfft_ctx_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -364,14 +367,14 @@ class FFTree:
         polynomials laid end to end (batched form, no reference counterpart)."""
         pin, out, pout, mem, stream, n = self._io(coeffs)
         assert n % count == 0
-        _check(lib().ecfft_enter_many(self._h, pin, pout, n // count, count, mem, stream))
+        _check(self._L.ecfft_enter_many(self._h, pin, pout, n // count, count, mem, stream))
         return out
 
     def exit(self, evals, count=1):
         """evaluations -> coefficients (src/fftree.rs:227-230)."""
         pin, out, pout, mem, stream, n = self._io(evals)
         assert n % count == 0
-        _check(lib().ecfft_exit_many(self._h, pin, pout, n // count, count, mem, stream))
+        _check(self._L.ecfft_exit_many(self._h, pin, pout, n // count, count, mem, stream))
         return out
 
     def extend(self, evals, moiety, count=1):
@@ -379,7 +382,7 @@ class FFTree:
         input as that many vectors laid end to end (batched form, no reference counterpart)."""
         pin, out, pout, mem, stream, total = self._io(evals)
         assert total % count == 0
-        _check(lib().ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
+        _check(self._L.ecfft_extend(self._h, pin, pout, total // count, int(moiety), count, mem, stream))
         return out
 
     # ---- the remaining FFTree algorithms (host numpy arrays; synchronous) ---------------------
@@ -389,7 +392,7 @@ class FFTree:
     def mextend(self, evals, moiety):
         """src/fftree.rs:138-141"""
         a = self._np(evals); out = np.empty_like(a)
-        _check(lib().ecfft_mextend(self._h, a.ctypes.data, out.ctypes.data, a.shape[0], int(moiety), 1, MEM_HOST, None))
+        _check(self._L.ecfft_mextend(self._h, a.ctypes.data, out.ctypes.data, a.shape[0], int(moiety), 1, MEM_HOST, None))
         return out
 
     def redc_z0(self, evals, a):
@@ -403,27 +406,27 @@ class FFTree:
     def _redc(self, evals, a, moiety):
         e = self._np(evals); a = self._np(a); out = np.empty_like(e)
         assert a.shape[0] == e.shape[0]
-        _check(lib().ecfft_redc(self._h, e.ctypes.data, a.ctypes.data, out.ctypes.data, e.shape[0], int(moiety), MEM_HOST, None))
+        _check(self._L.ecfft_redc(self._h, e.ctypes.data, a.ctypes.data, out.ctypes.data, e.shape[0], int(moiety), MEM_HOST, None))
         return out
 
     def modular_reduce(self, evals, a, c):
         """src/fftree.rs:286-289"""
         e = self._np(evals); a = self._np(a); c = self._np(c); out = np.empty_like(e)
         assert a.shape[0] == e.shape[0] == c.shape[0]
-        _check(lib().ecfft_modular_reduce(self._h, e.ctypes.data, a.ctypes.data, c.ctypes.data, out.ctypes.data, e.shape[0], MEM_HOST, None))
+        _check(self._L.ecfft_modular_reduce(self._h, e.ctypes.data, a.ctypes.data, c.ctypes.data, out.ctypes.data, e.shape[0], MEM_HOST, None))
         return out
 
     def vanish(self, domain):
         """src/fftree.rs:313-316"""
         d = self._np(domain)
         out = np.empty(self.field.shape(2 * d.shape[0]), self.field.dtype)
-        _check(lib().ecfft_vanish(self._h, d.ctypes.data, out.ctypes.data, d.shape[0], MEM_HOST, None))
+        _check(self._L.ecfft_vanish(self._h, d.ctypes.data, out.ctypes.data, d.shape[0], MEM_HOST, None))
         return out
 
     def degree(self, evals):
         """src/fftree.rs:195-198"""
         e = self._np(evals); deg = ctypes.c_size_t()
-        _check(lib().ecfft_degree(self._h, e.ctypes.data, e.shape[0], MEM_HOST, None, ctypes.byref(deg)))
+        _check(self._L.ecfft_degree(self._h, e.ctypes.data, e.shape[0], MEM_HOST, None, ctypes.byref(deg)))
         return deg.value
 
     def table_fma(self, x, y, m, which, t_off, t_stride, mode):
@@ -433,10 +436,10 @@ class FFTree:
         if y is not None:
             keep = y if _is_torch(y) else np.ascontiguousarray(y, self.field.dtype)     # keep the buffer alive across the call
             py = keep.data_ptr() if _is_torch(y) else keep.ctypes.data
-        _check(lib().ecfft_table_fma(self._h, pout, pin, py, n, m, which, t_off, t_stride, mode, mem, stream))
+        _check(self._L.ecfft_table_fma(self._h, pout, pin, py, n, m, which, t_off, t_stride, mode, mem, stream))
         return out
 
-    # ---- shards of one EXTEND split over P GPUs (in place; see ecfft_amd/distributed.py) -----
+    # ---- shards of one EXTEND split over P GPUs (in place; see tests/split_model.py for the model) -----
     def _inplace(self, x):
         if _is_torch(x):
             import torch
@@ -447,11 +450,11 @@ class FFTree:
 
     def extend_top_cyclic(self, shard, e, moiety, log_p, rank, recombine):
         ptr, mem, stream = self._inplace(shard)
-        _check(lib().ecfft_extend_top_cyclic(self._h, ptr, e, int(moiety), log_p, rank, int(recombine), mem, stream))
+        _check(self._L.ecfft_extend_top_cyclic(self._h, ptr, e, int(moiety), log_p, rank, int(recombine), mem, stream))
 
     def extend_local_block(self, shard, e, moiety, log_p):
         ptr, mem, stream = self._inplace(shard)
-        _check(lib().ecfft_extend_local_block(self._h, ptr, e, int(moiety), log_p, mem, stream))
+        _check(self._L.ecfft_extend_local_block(self._h, ptr, e, int(moiety), log_p, mem, stream))
 
     # ---- ONE transform split over the GPUs of a communicator (device tensors: this rank's block shard) -------------
     def _sharded(self, fn, comm, x, length, *extra):
@@ -466,29 +469,29 @@ class FFTree:
         """FFTree::extend of ONE length-e vector held block-distributed over the ranks of `comm` (C++ / RCCL path);
         cyclic_in / cyclic_out: the shard on that side is cyclic (local j' = global j' * world + rank), one exchange fewer each"""
         if not (cyclic_in or cyclic_out):
-            return self._sharded(lib().ecfft_extend_sharded, comm, x_block, e, int(moiety))
-        return self._sharded(lib().ecfft_extend_sharded_layout, comm, x_block, e, int(moiety), int(cyclic_in), int(cyclic_out))
+            return self._sharded(self._L.ecfft_extend_sharded, comm, x_block, e, int(moiety))
+        return self._sharded(self._L.ecfft_extend_sharded_layout, comm, x_block, e, int(moiety), int(cyclic_in), int(cyclic_out))
 
     def enter_sharded(self, comm, x_block, n):
-        return self._sharded(lib().ecfft_enter_sharded, comm, x_block, n)
+        return self._sharded(self._L.ecfft_enter_sharded, comm, x_block, n)
 
     def exit_sharded(self, comm, y_block, n):
-        return self._sharded(lib().ecfft_exit_sharded, comm, y_block, n)
+        return self._sharded(self._L.ecfft_exit_sharded, comm, y_block, n)
 
     # ---- benchmarking aid -------------------------------------------------------------------
     def low_map(self, direction):
         """32 / 16 / 0: the composite map the 1024-element low-level kernels run for the lowest ENTER (0) / EXIT (1) levels"""
-        return lib().ecfft_ctx_low_map(self._h, int(direction))
+        return self._L.ecfft_ctx_low_map(self._h, int(direction))
 
     def profile(self, on):
-        _check(lib().ecfft_profile_enable(self._h, int(on)))
+        _check(self._L.ecfft_profile_enable(self._h, int(on)))
 
     def profile_read(self):
         """[{name, launches, ms, alg_bytes}] per kernel class, from HIP events on the launch stream."""
         out = []
-        for c in range(lib().ecfft_profile_classes()):
+        for c in range(self._L.ecfft_profile_classes()):
             name = ctypes.create_string_buffer(64); n = ctypes.c_uint64(); ms = ctypes.c_double(); by = ctypes.c_double()
-            _check(lib().ecfft_profile_read(self._h, c, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+            _check(self._L.ecfft_profile_read(self._h, c, name, 64, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
             out.append({"name": name.value.decode(), "launches": n.value, "ms": ms.value, "alg_bytes": by.value})
         return out
 
@@ -496,9 +499,9 @@ class FFTree:
     def table(self, which, m=None):
         m = self.n if m is None else m
         cnt = ctypes.c_size_t()
-        _check(lib().ecfft_tree_table(self._h, m, which, None, 0, ctypes.byref(cnt)))
+        _check(self._L.ecfft_tree_table(self._h, m, which, None, 0, ctypes.byref(cnt)))
         out = np.zeros(self.field.shape(cnt.value), self.field.dtype)
-        _check(lib().ecfft_tree_table(self._h, m, which, out.ctypes.data, cnt.value, ctypes.byref(cnt)))
+        _check(self._L.ecfft_tree_table(self._h, m, which, out.ctypes.data, cnt.value, ctypes.byref(cnt)))
         return out
 
     def leaves(self, m=None):
@@ -508,9 +511,9 @@ class FFTree:
     def serialize(self, compress):
         """`FFTree::serialize_compressed` (compress=True) / `serialize_uncompressed` (src/fftree.rs:510-554) through the C ABI"""
         ln = ctypes.c_size_t()
-        _check(lib().ecfft_fftree_serialize(self._h, int(bool(compress)), None, 0, ctypes.byref(ln)))
+        _check(self._L.ecfft_fftree_serialize(self._h, int(bool(compress)), None, 0, ctypes.byref(ln)))
         buf = ctypes.create_string_buffer(ln.value)
-        _check(lib().ecfft_fftree_serialize(self._h, int(bool(compress)), buf, ln.value, ctypes.byref(ln)))
+        _check(self._L.ecfft_fftree_serialize(self._h, int(bool(compress)), buf, ln.value, ctypes.byref(ln)))
         return buf.raw[:ln.value]
 
     def rational_map(self, k):
@@ -518,7 +521,7 @@ class FFTree:
         if not hasattr(self, "_maps"):
             ln = max(self.n.bit_length() - 1, 1)
             num = np.zeros(self.field.shape(3 * ln), self.field.dtype); den = np.zeros(self.field.shape(3 * ln), self.field.dtype)
-            _check(lib().ecfft_tree_rational_maps(self._h, num.ctypes.data, den.ctypes.data))
+            _check(self._L.ecfft_tree_rational_maps(self._h, num.ctypes.data, den.ctypes.data))
             self._maps = (num, den)
         num, den = self._maps
         return num[3 * k:3 * k + 3], den[3 * k:3 * k + 3]

@@ -160,9 +160,13 @@ void ecfft_comm_destroy(ecfft_comm* comm);
 int ecfft_comm_abort(ecfft_comm* comm);
 /* Link striping of the big pairwise exchanges of a split ENTER / EXIT (round 5): a message travels as `world` slices, slice k via
  * rank k, in two grouped exchanges, so that every link of the xGMI mesh carries 1/world of it per phase — applied to an exchange only
- * when its most loaded link gets lighter by at least `min_gain_bytes` over both phases.  Default 4 MiB (>= 85 us at 48 GB/s against one
- * more exchange latency); 0 = whenever striping moves fewer bytes over the most loaded link; SIZE_MAX = never.  Every rank of the
- * communicator must use the same value (the decision is taken locally from the call's message pattern).  Returns ECFFT_OK. */
+ * when its most loaded link gets lighter by at least `min_gain_bytes` over both phases.  OFF by default (SIZE_MAX = never; round 6:
+ * bit-exact over every transport the tests have, never yet timed on xGMI — it doubles the bytes a rank injects and adds an exchange).
+ * 4 MiB is the threshold the projection suggests (>= 85 us at 48 GB/s against one more exchange latency); 0 = whenever striping moves
+ * fewer bytes over the most loaded link.  Every rank of the communicator must use the same value (each rank decides locally from the
+ * call's message pattern): the ranks compare it in the agreement that precedes the first call of every sharded call shape, and a
+ * mismatch fails that call on all of them with ECFFT_ERR_HIP.  Only BEFORE the communicator has carried its first exchange:
+ * ECFFT_ERR_BAD_ARG afterwards. */
 int ecfft_comm_set_link_striping(ecfft_comm* comm, size_t min_gain_bytes);
 int ecfft_comm_rank(const ecfft_comm* comm);
 int ecfft_comm_world(const ecfft_comm* comm);

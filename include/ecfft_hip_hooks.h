@@ -18,8 +18,8 @@ extern "C" {
  * differ from the pointwise isogeny-chain formula the sharded builds use; 0 = identical, -1 = error */
 long ecfft_selfcheck_pointwise_z(ecfft_ctx* ctx, size_t m);
 
-/* MEASUREMENT ONLY: one rank of a `world`-rank job timed on its own.  Every exchange with a remote peer costs delay_us + (largest
- * message of the exchange) / link_gbps GB/s as a spinning kernel on the caller's stream, and the rank's own send buffers are copied
+/* MEASUREMENT ONLY: one rank of a `world`-rank job timed on its own.  Every exchange with a remote peer costs delay_us + (bytes on
+ * the exchange's most loaded LINK: the messages to one peer add up) / link_gbps GB/s as a spinning kernel on the caller's stream, and the rank's own send buffers are copied
  * into its receive buffers: the stream's timeline is that of a rank whose peers answer after exactly the modelled time; the
  * RESULTS of a sharded call on such a communicator are meaningless (tools/split_project.py: per-rank compute, exchanges, bytes and
  * exposed communication time of the split transforms without multi-GPU hardware).  link_gbps = 0: latency only. */

@@ -1,5 +1,5 @@
 """Worker for tests/test_distributed.py: run with torch.distributed.run, gloo backend, CPU only.
-Checks ecfft_amd.distributed.extend_sharded (block<->cyclic all-to-all orchestration) against the
+Checks tests/split_model.py extend_sharded (block<->cyclic all-to-all orchestration) against the
 oracle's FFTree::extend with a numpy local-stage backend built from the reference's own matrices
 (decompose_matrices / recombine_matrices, src/fftree.rs:26-27, 83-97, 104-118)."""
 import os
@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import oracle  # noqa: E402
-from ecfft_amd import distributed as D  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import split_model as D  # noqa: E402  (the Python model of the split: test infrastructure)
 
 
 class OracleOps:

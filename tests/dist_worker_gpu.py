@@ -3,7 +3,7 @@ Runs the C++ multi-GPU path of the C ABI (ecfft_extend_sharded / ecfft_enter_sha
 pack / unpack operators, cyclic-shard stage kernels, block-local fused passes) with a CALLBACK transport — the exchanges are
 torch.distributed point-to-point calls staged through host memory, because RCCL refuses several ranks on one device — and
 compares every rank's shard with the single-GPU transforms of the same context, bit for bit.  The Python model of the same
-algorithm (ecfft_amd.distributed.extend_sharded with HipOps) is run next to it for the split EXTEND."""
+algorithm (tests/split_model.py extend_sharded with HipOps) is run next to it for the split EXTEND."""
 import os
 import sys
 
@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 
 import ecfft_amd  # noqa: E402
 from ecfft_amd import distributed as D  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import split_model as M  # noqa: E402  (the Python model of the split: test infrastructure)
 
 
 def synth(field, n, seed):
@@ -70,7 +72,7 @@ def main():
         for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):
             want = tree.extend(full, moiety)
             ok = check(f"extend_sharded {moiety}", tree.extend_sharded(comm, mine.clone(), n, moiety), want) and ok
-            ok = check(f"model extend {moiety}", D.extend_sharded(D.HipOps(tree), mine.clone(), n, moiety), want) and ok
+            ok = check(f"model extend {moiety}", M.extend_sharded(M.HipOps(tree), mine.clone(), n, moiety), want) and ok
         # cyclic-in / cyclic-out variants on the full context (one exchange fewer each)
         cyc = full[rank::world].contiguous()
         for moiety in (ecfft_amd.Moiety.S1, ecfft_amd.Moiety.S0):

@@ -1,5 +1,5 @@
 """Multi-process tests of the N>1 paths on CPU (gloo): the split-EXTEND orchestration
-(ecfft_amd/distributed.py: block<->cyclic all_to_all_single + local stage calls) at world sizes 2 and 4."""
+(tests/split_model.py: block<->cyclic all_to_all_single + local stage calls) at world sizes 2 and 4."""
 import os
 import socket
 import subprocess
@@ -345,8 +345,8 @@ def test_full_context_fuses_its_cyclic_stages(field, e, P, monkeypatch, hooks_li
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2),    # chunk 2^20 runs the two-halves schedule
-                                       ("secp256k1", 1 << 20, 8)])   # last: the BASELINE metric's size (configs[2]) over P = 8
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])    # chunk 2^20 runs the two-halves schedule
+# (the BASELINE metric's size, secp256k1 2^20 over P = 8, is held against the CPU oracle directly: tests/test_gpu_parity.py::test_shard_contexts_2e20_over_8_ranks_vs_oracle)
 def test_enter_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_enter_shard: P sharded ENTER-only contexts (chain up to n/P + the rank's share of the log2 P top trees) driven
     as the ranks of one process == the single-GPU ENTER of a full context, bit for bit; smaller HBM footprint; other calls refused"""
@@ -388,8 +388,8 @@ def test_enter_shard_context_on_one_gpu(field, n, P):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("field,n,P", [("secp256k1", 1 << 12, 2), ("secp256k1", 1 << 13, 4), ("m31", 1 << 16, 8), ("m31", 1 << 20, 4), ("secp256k1", 1 << 9, 8),
-                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2),    # chunk 2^20 runs the two-halves schedule
-                                       ("secp256k1", 1 << 20, 8)])   # last: the BASELINE metric's size (configs[2]) over P = 8
+                                       ("secp256k1", 1 << 17, 8), ("m31", 1 << 22, 16), ("m31", 1 << 21, 2)])    # chunk 2^20 runs the two-halves schedule
+# (the BASELINE metric's size, secp256k1 2^20 over P = 8, is held against the CPU oracle directly: tests/test_gpu_parity.py::test_shard_contexts_2e20_over_8_ranks_vs_oracle)
 def test_exit_shard_context_on_one_gpu(field, n, P):
     """ecfft_build_exit_shard (collective, distributed build of z0z0_rem_xnn_s): P sharded EXIT-only contexts as the ranks of one
     process == the single-GPU EXIT of a full context on arbitrary evaluations, bit for bit; other calls refused"""
@@ -499,7 +499,8 @@ def test_split_exit_runs_its_pair_level_redundantly_with_one_exchange(field, n, 
 def test_link_striping_of_the_pairwise_exchanges_is_bit_exact(field, n, P, monkeypatch, hooks_lib):
     """round 5: the big PAIRWISE exchanges of a split ENTER / EXIT (the level's re-distribution, the pair level, small-group
     all-to-alls) travel striped over every link of the mesh — slice k of a message via rank k, two grouped exchanges
-    (Transport::exchange_striped) — when that takes >= 2 MiB off the most loaded link.  Here the threshold is 0 (test switch), so
+    (Transport::exchange_striped) — when that takes at least the communicator's threshold off the most loaded link (opt-in since round 6:
+    ecfft_comm_set_link_striping; the projection suggests 4 MiB).  Here the threshold is 0 (test switch), so
     every eligible exchange of these small transforms is striped: results must equal the single-GPU transforms bit for bit, on
     shard contexts and on a full context, and more exchanges must have been issued than without striping."""
     import torch
@@ -548,7 +549,8 @@ def test_link_striping_of_the_pairwise_exchanges_is_bit_exact(field, n, P, monke
 @pytest.mark.gpu
 def test_link_striping_threshold_through_the_abi():
     """ecfft_comm_set_link_striping on the SHIPPED library (no environment switch): 0 stripes every exchange that striping makes
-    lighter, SIZE_MAX none, the default (4 MiB) none at this small size — same bits in all three, more grouped exchanges only with 0"""
+    lighter, SIZE_MAX none, the default (off since round 6) none — same bits in all three, more grouped exchanges only with 0.  Also: the
+    threshold is frozen once the communicator has carried an exchange (ECFFT_ERR_BAD_ARG)."""
     import torch
     import ecfft_amd
     F = ecfft_amd.FIELDS["secp256k1"]
@@ -570,12 +572,54 @@ def test_link_striping_threshold_through_the_abi():
             comm.stats(True)
             got[rank] = esh.enter_sharded(comm, x[rank * c:(rank + 1) * c].clone(), n)
             got[("nx", rank)] = comm.stats()["exchanges"]
+            try:
+                comm.set_link_striping(0)
+                got[("late", rank)] = "accepted"
+            except Exception as ex:
+                got[("late", rank)] = str(ex)
 
         _thread_ranks(P, body)
         for r in range(P):
             assert torch.equal(got[r], want[r * c:(r + 1) * c]), (name, r)
+            assert got[("late", r)] != "accepted", "the striping threshold must be frozen after the first exchange"
         counts[name] = got[("nx", 0)]
     assert counts["default"] == counts["never"] == 8 and counts["always"] > 8, counts
+
+
+@pytest.mark.gpu
+def test_link_striping_threshold_mismatch_fails_every_rank():
+    """'the same threshold on every rank' was an unchecked contract, and exchange_striped decides locally.  The ranks now
+    compare it in the agreement that precedes the first call of a sharded shape: one rank with another value makes that call fail
+    on EVERY rank (no hang, no differently striped exchanges), and a communicator whose ranks agree works."""
+    import torch
+    import ecfft_amd
+    F = ecfft_amd.FIELDS["secp256k1"]
+    n, P = 1 << 13, 4
+    c = n // P
+    a = np.random.default_rng(6).integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+    x = torch.from_numpy(a.view(np.int64)).cuda()
+    want = F.build_fftree(n).enter(x)
+    torch.cuda.synchronize()
+    got = {}
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        if rank == 1:
+            comm.set_link_striping(0)
+        esh = F.build_enter_shard(n, P, rank)
+        try:
+            esh.enter_sharded(comm, x[rank * c:(rank + 1) * c].clone(), n)
+            got[rank] = "ok"
+        except ecfft_amd.fftree.EcfftError as ex:
+            got[rank] = f"error: {ex}"
+        comm2 = make_comm()
+        comm2.set_link_striping(0)
+        got[("second", rank)] = esh.enter_sharded(comm2, x[rank * c:(rank + 1) * c].clone(), n)
+
+    _thread_ranks(P, body)
+    for r in range(P):
+        assert got[r].startswith("error"), (r, got[r])
+        assert torch.equal(got[("second", r)], want[r * c:(r + 1) * c]), r
 
 
 @pytest.mark.gpu

@@ -72,6 +72,89 @@ def test_degree(trees, field):
         assert gt.degree(ev) == 5
 
 
+# ------------------------------------------------------------------------------------ at scale (round 6)
+class _OracleAlgorithms17:
+    """VERDICT r05 missing #4: the f3 wrappers never met the oracle above 2^11 — the column passes, the 1024-element tiles, the matrix-core
+    phases and the device batch inversion at scale were reached through ENTER / EXIT only.  The oracle's 2^17 trees (secp256k1: ~10 s
+    to build) and the expected sides of MEXTEND (e = 2^16), REDC_z0 / z1 with an arbitrary `a`, MOD, VANISH (nd = 2^15) and DEGREE at
+    n = 2^16, computed on a background host thread while the small tests above run (ctypes releases the GIL)."""
+    LOG_TREE, LOG_N = 17, 16
+
+    def __init__(self, oracle_mod, field):
+        import threading
+        self.o, self.F = oracle_mod, oracle_mod.field(field)
+        self.res, self.err = {}, []
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def inputs(self):
+        F, n = self.F, 1 << self.LOG_N
+        big = lambda k, seed, nz=False: _rand_big(F, k, seed, nz)      # noqa: E731
+        d = 40_000
+        cd = big(n, 5, True); cd[d + 1:] = 0
+        return dict(x=big(n, 1), ev=big(n, 2), a=big(n, 3, True), c=big(n, 4), dom=big(n // 2, 6, True), coeffs_deg=cd, deg=d)
+
+    def _run(self):
+        try:
+            o, i = self.o, self.inputs()
+            ot = self.F.build_fftree(1 << self.LOG_TREE)
+            self.res = dict(mext_s1=ot.mextend(i["x"], o.S1), mext_s0=ot.mextend(i["x"], o.S0),
+                            redc_z0=ot.redc(i["ev"], i["a"], o.S0), redc_z1=ot.redc(i["ev"], i["a"], o.S1),
+                            mod=ot.modular_reduce(i["ev"], i["a"], i["c"]), vanish=ot.vanish(i["dom"]),
+                            ev_deg=ot.enter(i["coeffs_deg"]))
+            self.res["deg"] = ot.degree(self.res["ev_deg"])
+        except Exception as e:  # pragma: no cover
+            self.err.append(e)
+
+    def get(self):
+        self.th.join()
+        assert not self.err, self.err
+        return self.res
+
+
+def _rand_big(F, n, seed, nonzero=False):
+    """large arrays without a Python loop: any 256-bit pattern below p is a valid element (top bit cleared); nonzero: low limb |= 1"""
+    rng = np.random.default_rng(0x5EED1700 + seed)
+    if F.limbs == 1:
+        return rng.integers(1 if nonzero else 0, 2**31 - 1, n, dtype=np.uint32)
+    a = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); a[:, 3] >>= np.uint64(1)
+    if nonzero:
+        a[:, 0] |= np.uint64(1)
+    return a
+
+
+_alg17 = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def alg17(oracle_mod):
+    """started with the first test of this module"""
+    if not _alg17:
+        for f in FIELDS:
+            _alg17[f] = _OracleAlgorithms17(oracle_mod, f)
+    return _alg17
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_algorithms_at_2e16_vs_oracle(alg17, oracle_mod, field):
+    """MEXTEND, REDC_z0 / z1 (arbitrary a: the device batch inversion of 2^15 elements), MOD, VANISH (nd = 2^15) and DEGREE at n = 2^16 on
+    a 2^17 tree against the oracle's restatement of src/fftree.rs:128-141, 169-198, 261-316, element for element"""
+    import ecfft_amd as G
+    job = alg17[field]
+    gt = G.FIELDS[field].build_fftree(1 << job.LOG_TREE)
+    i = job.inputs()
+    want = job.get()
+    assert np.array_equal(gt.mextend(i["x"], G.Moiety.S1), want["mext_s1"])
+    assert np.array_equal(gt.mextend(i["x"], G.Moiety.S0), want["mext_s0"])
+    assert np.array_equal(gt.redc_z0(i["ev"], i["a"]), want["redc_z0"])
+    assert np.array_equal(gt.redc_z1(i["ev"], i["a"]), want["redc_z1"])
+    assert np.array_equal(gt.modular_reduce(i["ev"], i["a"], i["c"]), want["mod"])
+    assert np.array_equal(gt.vanish(i["dom"]), want["vanish"])
+    assert want["deg"] == i["deg"]
+    assert gt.degree(want["ev_deg"]) == i["deg"]
+    assert np.array_equal(gt.enter(i["coeffs_deg"]), want["ev_deg"])
+
+
 @pytest.mark.parametrize("field", FIELDS)
 def test_algorithm_errors(trees, field):
     F, ot, gt, G = trees[field]

@@ -29,9 +29,9 @@ class _OracleHeadline:
     serves the 2^19 transforms — and, since round 5, M31 n = 2^24 (configs[4]) and 2^22 on its 2^24 tree.  Inputs are seeded;
     `get()` joins and returns {log_n: expected outputs} (the expected side of src/lib.rs:108-152, 239-264)."""
 
-    def __init__(self, oracle_mod, field, log_top, sizes):
+    def __init__(self, oracle_mod, field, log_top, sizes, second=()):
         import threading
-        self.o, self.field, self.log_top, self.sizes = oracle_mod, field, log_top, sizes
+        self.o, self.field, self.log_top, self.sizes, self.second = oracle_mod, field, log_top, sizes, second
         self.F = oracle_mod.field(field)
         self.res, self.err = {}, []
         self.th = threading.Thread(target=self._run, daemon=True)
@@ -46,6 +46,8 @@ class _OracleHeadline:
             c, r = self.inputs(log_n)
             h = r[: (1 << log_n) // 2]
             self.res[log_n] = dict(enter=ot.enter(c), exit=ot.exit(r), ext_s1=ot.extend(h, self.o.S1), ext_s0=ot.extend(h, self.o.S0))
+            if log_n in self.second:          # round 6: a second polynomial per size, for the batched calls (ecfft_enter_many / _exit_many)
+                self.res[log_n]["enter2"] = ot.enter(r)
         except Exception as e:  # pragma: no cover
             self.err.append(e)
 
@@ -101,8 +103,8 @@ _oracle_headline = {}
 @pytest.fixture(scope="module")
 def oracle_headline(oracle_mod, gpu):
     if not _oracle_headline:
-        _oracle_headline["secp256k1"] = _OracleHeadline(oracle_mod, "secp256k1", 20, (20, 19))
-        _oracle_headline["m31"] = _OracleHeadline(oracle_mod, "m31", 24, (24, 22))
+        _oracle_headline["secp256k1"] = _OracleHeadline(oracle_mod, "secp256k1", 20, (20, 19), second=(20, 19))
+        _oracle_headline["m31"] = _OracleHeadline(oracle_mod, "m31", 24, (24, 22), second=(22,))
         _oracle_headline["extend22"] = _OracleExtend22(oracle_mod)
     return _oracle_headline
 
@@ -407,6 +409,68 @@ def test_secp_headline_sizes_vs_oracle(gpu, gpu_tree, oracle_mod, oracle_headlin
     evd = t.enter(d)
     assert np.array_equal(evd.cpu().numpy().view(np.uint64), want["enter"])
     assert np.array_equal(t.exit(evd).cpu().numpy().view(np.uint64), c)
+
+
+@pytest.mark.parametrize("field,log_n,count", [("secp256k1", 19, 2), ("secp256k1", 19, 3), ("secp256k1", 20, 2), ("m31", 22, 2), ("m31", 22, 3)])
+def test_batched_calls_at_headline_sizes_vs_oracle(gpu, gpu_tree, oracle_headline, field, log_n, count):
+    """round 6 (VERDICT r05 missing #4): ecfft_enter_many / ecfft_exit_many above n = 8 192 against the CPU oracle ELEMENT FOR ELEMENT.
+    A batch does not take the two-halves schedule of a single transform: an ODD count runs every level as one large launch on one
+    stream (2^19 x 3: 1 536-tile launches), an EVEN count runs as two half-batches on two streams (round 6) — neither path met
+    the oracle before, only the bench's round trip.  Polynomials: c, r (and c again) of _OracleHeadline; expected: the oracle's
+    ENTER of c and of r, its EXIT of r, and c = EXIT(ENTER(c)) with the oracle's ENTER(c) as the input."""
+    import torch
+    n = 1 << log_n
+    want = oracle_headline[field].get()[log_n]
+    c, r = oracle_headline[field].inputs(log_n)
+    t = gpu_tree(field, n)
+    ins = [c, r, c][:count]
+    outs = [want["enter"], want["enter2"], want["enter"]][:count]
+    view = (lambda a: a.view(np.int64)) if field == "secp256k1" else (lambda a: a.view(np.int32))
+    back = (lambda a: a.view(np.uint64)) if field == "secp256k1" else (lambda a: a.view(np.uint32))
+    d = torch.from_numpy(view(np.concatenate(ins))).cuda()
+    ev = t.enter(d, count)
+    assert np.array_equal(back(ev.cpu().numpy()), np.concatenate(outs))
+    e_in = [r, want["enter"], r][:count]
+    e_out = [want["exit"], c, want["exit"]][:count]
+    d = torch.from_numpy(view(np.concatenate(e_in))).cuda()
+    co = t.exit(d, count)
+    assert np.array_equal(back(co.cpu().numpy()), np.concatenate(e_out))
+    # host buffers through the same calls (staging path of the ABI)
+    if count == 2 and log_n < 22:
+        assert np.array_equal(t.enter(np.concatenate(ins), count), np.concatenate(outs))
+
+
+def test_shard_contexts_2e20_over_8_ranks_vs_oracle(gpu, oracle_headline):
+    """round 6 (VERDICT r05 missing #4): the sharded transforms at the BASELINE metric's size (secp256k1 n = 2^20, configs[2]) over P = 8
+    ranks against the CPU ORACLE directly — ENTER-shard contexts on the oracle's input c, EXIT-shard contexts (collective build) on
+    arbitrary evaluations r — every rank's block element for element.  (tests/test_distributed.py holds the same contexts against the
+    single-GPU transform at the other sizes; until round 6 this size was compared that way too: one hop longer than needed.)"""
+    import torch
+    from test_distributed import _thread_ranks
+    log_n, P = 20, 8
+    n = 1 << log_n
+    c_ = n // P
+    want = oracle_headline["secp256k1"].get()[log_n]
+    c, r = oracle_headline["secp256k1"].inputs(log_n)
+    F = gpu.FIELDS["secp256k1"]
+    x = torch.from_numpy(c.view(np.int64)).cuda()
+    y = torch.from_numpy(r.view(np.int64)).cuda()
+    got = {}
+
+    def body(rank, make_comm):
+        comm = make_comm()
+        esh = F.build_enter_shard(n, P, rank)
+        got[("enter", rank)] = esh.enter_sharded(comm, x[rank * c_:(rank + 1) * c_].clone(), n)
+        del esh
+        xsh = F.build_exit_shard(n, comm)
+        got[("exit", rank)] = xsh.exit_sharded(comm, y[rank * c_:(rank + 1) * c_].clone(), n)
+
+    _thread_ranks(P, body)
+    torch.cuda.synchronize()
+    for rk in range(P):
+        sl = slice(rk * c_, (rk + 1) * c_)
+        assert np.array_equal(got[("enter", rk)].cpu().numpy().view(np.uint64), want["enter"][sl]), ("enter", rk)
+        assert np.array_equal(got[("exit", rk)].cpu().numpy().view(np.uint64), want["exit"][sl]), ("exit", rk)
 
 
 @pytest.mark.parametrize("log_n", [22, 24])
