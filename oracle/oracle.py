@@ -26,7 +26,10 @@ def build():
 class _Field:
     def __init__(self, name, prefix, dtype, limbs):
         self.name, self.prefix, self.dtype, self.limbs = name, prefix, np.dtype(dtype), limbs
-        path = os.path.join(_DIR, f"libecfft_oracle_{name}.so")
+        # ECFFT_ORACLE_LIBDIR: another build of the same sources (oracle/asan: `make asan`, the AddressSanitizer + UBSan build that
+        # tests/test_oracle.py runs in a child process with libasan preloaded)
+        libdir = os.environ.get("ECFFT_ORACLE_LIBDIR") or _DIR
+        path = os.path.join(libdir, f"libecfft_oracle_{name}.so")
         if not os.path.exists(path):
             build()
         self.lib = ctypes.CDLL(path)

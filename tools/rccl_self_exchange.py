@@ -12,6 +12,7 @@ import sys
 import time
 
 import torch
+import torch.distributed  # noqa: F401  (maps torch's bundled librccl)
 
 SIZES = [4, 64 << 10, 4 << 20, 16 << 20]
 MSGS = [1, 7]
@@ -43,7 +44,6 @@ def main():
 
     torch.cuda.init()
     _ = torch.zeros(1, device="cuda")          # librccl gets mapped with torch's HIP runtime
-    import torch.distributed  # noqa: F401  (maps torch's bundled librccl)
     R, name = load_rccl()
     R.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
     R.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
