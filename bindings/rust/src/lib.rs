@@ -75,7 +75,7 @@ pub mod ffi {
         pub fn ecfft_build_exit_shard_opts(field: i32, n: usize, device: i32, comm: *mut EcfftComm, flags: i32, out: *mut *mut EcfftCtx) -> i32; // flags: 1 = ECFFT_EXIT_SHARD_MIN_MEMORY
         pub fn ecfft_comm_set_rccl_library(path: *const std::os::raw::c_char) -> i32; // before the first communicator; NULL = default
         pub fn ecfft_comm_abort(comm: *mut EcfftComm) -> i32;
-        pub fn ecfft_comm_set_link_striping(comm: *mut EcfftComm, min_gain_bytes: usize) -> i32; // usize::MAX = never, 0 = whenever it helps
+        pub fn ecfft_comm_set_link_striping(comm: *mut EcfftComm, min_gain_bytes: usize) -> i32; // usize::MAX = never (the default since round 6), 0 = whenever it helps; same value on every rank (checked in the ranks' first vote); ERR_BAD_ARG once the communicator has carried an exchange
         pub fn ecfft_extend_sharded(ctx: *mut EcfftCtx, comm: *mut EcfftComm, input: *const c_void, out: *mut c_void, e: usize, moiety: i32, stream: *mut c_void) -> i32;
         pub fn ecfft_extend_sharded_layout(ctx: *mut EcfftCtx, comm: *mut EcfftComm, input: *const c_void, out: *mut c_void, e: usize, moiety: i32, in_layout: i32, out_layout: i32, stream: *mut c_void) -> i32; // 0 block, 1 cyclic
         pub fn ecfft_enter_sharded(ctx: *mut EcfftCtx, comm: *mut EcfftComm, coeffs: *const c_void, evals: *mut c_void, n: usize, stream: *mut c_void) -> i32;

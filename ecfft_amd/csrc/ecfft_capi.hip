@@ -659,6 +659,11 @@ int wire_read(int field, const uint8_t* data, size_t len, int compress, int devi
                 rc = guarded([&] { return table_of(ch, lv.n, which, got.data(), lv.cnt[which], nullptr, true); });
                 if (rc != ECFFT_OK) return rc;
                 const size_t skip = which == ECFFT_TBL_F ? 1 : 0;           // heap index 0 is unused (src/utils.rs:228-252)
+                if (verify && which == ECFFT_TBL_F && lv.cnt[which] > 0) {  // ... and zero in every tree the crate builds (src/fftree.rs:50, 471): a verified
+                    bool zero0 = true;                                      // file is byte for byte what serialize writes (tests: mutated files)
+                    for (size_t b = 0; b < eb; ++b) zero0 = zero0 && lv.tbl[which][b] == 0;
+                    if (!zero0) { fprintf(stderr, "ecfft: entry 0 of f of the %zu-leaf subtree in the file is not zero\n", lv.n); return ECFFT_ERR_BAD_ARG; }
+                }
                 if (lv.cnt[which] > skip && memcmp((const uint8_t*)got.data() + skip * eb, lv.tbl[which] + skip * eb, (lv.cnt[which] - skip) * eb) != 0) {
                     fprintf(stderr, "ecfft: table %d of the %zu-leaf subtree in the file differs from the one rebuilt from its point set\n", which, lv.n);
                     return ECFFT_ERR_BAD_ARG;

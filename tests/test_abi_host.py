@@ -153,3 +153,45 @@ def test_rccl_library_can_only_be_chosen_before_the_first_communicator():
         "print('RCCL_LIB_OK')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "RCCL_LIB_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def _c_prototypes(header_name):
+    """name -> number of parameters of every function the header declares (comments stripped; `void` = 0)"""
+    src = open(os.path.join(ROOT, "include", header_name)).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+int\s*\(\*[^;]*;", " ", src, flags=re.S)             # the exchange callback type is not a function of the library
+    out = {}
+    for m in re.finditer(r"\b(ecfft_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", src, re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_rust_binding_declares_the_header(prod):
+    """the Rust side (bindings/rust, source that has never met a compiler here) must stay ONE `cargo test` away from
+    pinning the oracle.  Its `extern "C"` block is compared with include/ecfft_hip.h mechanically: every function it declares exists
+    in the header with the same number of parameters, and every entry point of the reference surface and of the multi-GPU path is
+    declared (measurement hooks and the building blocks a Rust host has no use for may be absent, by name)."""
+    proto = _c_prototypes("ecfft_hip.h")
+    rs = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    block = block[:block.index("\n    }")]
+    rust = {}
+    for m in re.finditer(r"pub fn (ecfft_[a-z_0-9]+)\s*\((.*?)\)\s*(?:->\s*[A-Za-z0-9_]+\s*)?;", block, re.S):
+        args = m.group(2).strip()
+        rust[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    assert len(rust) >= 35, sorted(rust)
+    for name, n in rust.items():
+        assert name in proto, f"bindings/rust declares {name}, which include/ecfft_hip.h does not"
+        assert proto[name] == n, f"{name}: {n} parameters in bindings/rust/src/lib.rs, {proto[name]} in include/ecfft_hip.h"
+    optional = {"ecfft_field", "ecfft_build_points", "ecfft_table_fma", "ecfft_extend_top_cyclic", "ecfft_extend_local_block", "ecfft_comm_init_callback",
+                "ecfft_comm_stats_enable", "ecfft_comm_stats_read", "ecfft_profile_enable", "ecfft_profile_classes", "ecfft_profile_read",
+                "ecfft_elems_to_standard", "ecfft_elems_from_standard", "ecfft_mul_ceiling", "ecfft_shader_clock", "ecfft_device_info"}
+    missing = sorted(set(proto) - set(rust) - optional)
+    assert not missing, f"include/ecfft_hip.h entry points without a Rust declaration: {missing}"
+    # the pin program and the parity test use only what the binding exposes
+    for f in ("tests/parity.rs", "benches/fftree.rs"):
+        txt = open(os.path.join(ROOT, "bindings", "rust", f)).read()
+        for name in re.findall(r"ffi::(ecfft_[a-z_0-9]+)", txt):
+            assert name in rust, (f, name)

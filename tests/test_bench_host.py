@@ -130,6 +130,41 @@ def test_gpus2_headline_is_the_split_transform(transport):
 
 
 @pytest.mark.gpu
+def test_the_drivers_scale_command_with_8_ranks_dry_run():
+    """the command the driver launches on an 8-GPU node — `python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8 --steps K --warmup W`, nothing else on the line: n = 2^20 split ENTER+EXIT (9 exchanges per step), e = 2^22 split EXTEND
+    (4), three kinds of contexts per rank — run END TO END with 8 ranks sharing this box's one GPU: gloo process group, the library's
+    RCCL transport bound to the stand-in library.  Functional only (times mean nothing).  The first real 8-GPU run must not be the
+    first 8-rank run.  Needs ~25 GB of HBM for the eight ranks' contexts: skipped on a busy / small device."""
+    import socket
+    import subprocess
+    import torch
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 40 << 30:
+        pytest.skip(f"only {free >> 30} GiB of HBM free")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    stub = os.path.join(ROOT, "tests", "stub_rccl", "librccl_stub.so")
+    if not os.path.exists(stub):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", stub, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp"), "-lrt"], check=True)
+    env = dict(os.environ, ECFFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ECFFT_BENCH_TRANSPORT="rccl", ECFFT_BENCH_RCCL_LIB=stub)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["headline"] == "split" and d["scaling"] == "strong" and d["steps"] == 2
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["n"] == 1 << 20
+    sp = d["split"]
+    assert sp["ranks"] == 8 and sp["status"] == 0 and "stand-in" in sp["transport"]
+    ee, ex = sp["enter_exit"], sp["extend"]
+    assert ee["round_trip_ok"] is True and ee["ranks_seen_by_transport"] == 8 and ee["phases"]["exchanges_per_step"] == 9
+    assert ex["round_trip_ok"] is True and ex["ranks_seen_by_transport"] == 8 and ex["phases"]["exchanges_per_step"] == 4
+    assert d["value"] == ee["value"] and d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+
+
+@pytest.mark.gpu
 def test_a_stuck_split_part_costs_the_split_object_not_the_line():
     """The split part is the only code a one-GPU lease cannot run over multi-rank RCCL.  If it hangs (or raises) on a real
     node, the replica measurement that precedes it must still be printed: a watchdog emits the line with `split.error`."""

@@ -91,3 +91,74 @@ def test_c_deserializer_rejects_bad_files(oracle_tree, field):
     # compressed files carry no inverse tables; the loaded tree has them (regenerated, src/fftree.rs:620-628)
     t = S.deserialize_fftree(P, S.serialize_fftree(ot, P, True), True)
     assert np.array_equal(t.table(S.T_XNN_S_INV, 16), ot.table(S.T_XNN_S_INV, 16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("compress", [True, False])
+def test_c_deserializer_survives_mutated_files(oracle_tree, field, compress):
+    """the wire-format reader takes untrusted input (counterpart: /root/reference/src/fftree.rs:600-660, which trusts
+    it).  2 500 seeded mutations of a valid file per (field, mode) — bit flips, byte stores, random and extreme length prefixes,
+    truncations, insertions, duplicated and swapped regions, spliced files of another size — through ecfft_fftree_deserialize with
+    verify = 1: every call returns a status (no crash, no hang, no HIP error), and a file that is ACCEPTED is canonical — the loaded
+    tree writes the very bytes it was read from (so nothing in an accepted file was ignored or repaired)."""
+    import ctypes
+    import ecfft_amd
+    from ecfft_amd import fftree as FT
+    from ecfft_amd import serialize as S
+    P = ecfft_amd.FIELDS[field]
+    L = FT.lib()
+    F, ot = oracle_tree(field, 8)
+    F4, ot4 = oracle_tree(field, 4)
+    good, other = S.serialize_fftree(ot, P, compress), S.serialize_fftree(ot4, P, compress)
+    rng = np.random.default_rng(0x5EED0F00 + 2 * P.id + int(compress))
+    eb = P.elem_bytes
+    # offsets of the u64 length prefixes of the first level (f, recombine, decompose, maps, ...): mutations aim at structure too
+    prefixes = [0, 8 + 16 * eb, 8 + 16 * eb + 8 + 32 * eb]
+
+    def mutate(b):
+        b = bytearray(b)
+        k = int(rng.integers(0, 10))
+        n = len(b)
+        if k == 0:                                   # flip 1..4 bits anywhere
+            for _ in range(int(rng.integers(1, 5))):
+                i = int(rng.integers(0, n)); b[i] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:                                 # store random bytes
+            i = int(rng.integers(0, n)); m = int(rng.integers(1, 17)); b[i:i + m] = rng.bytes(min(m, n - i))
+        elif k == 2:                                 # a length prefix becomes something else (small, huge, 2^63, all ones)
+            i = prefixes[int(rng.integers(0, len(prefixes)))] if rng.integers(0, 2) else 8 * int(rng.integers(0, n // 8))
+            v = [0, 1, 3, 7, 16, 17, 1 << 20, (1 << 61) + 1, 1 << 63, (1 << 64) - 1, int(rng.integers(0, 1 << 62))][int(rng.integers(0, 11))]
+            b[i:i + 8] = v.to_bytes(8, "little")
+        elif k == 3:                                 # truncate
+            b = b[:int(rng.integers(0, n))]
+        elif k == 4:                                 # insert
+            i = int(rng.integers(0, n + 1)); b[i:i] = rng.bytes(int(rng.integers(1, 65)))
+        elif k == 5:                                 # duplicate a region in place
+            i, m = int(rng.integers(0, n)), int(rng.integers(1, 200)); b[i:i] = b[i:i + m]
+        elif k == 6:                                 # swap two aligned elements
+            i, j = eb * int(rng.integers(0, n // eb - 1)), eb * int(rng.integers(0, n // eb - 1)); b[i:i + eb], b[j:j + eb] = b[j:j + eb], b[i:i + eb]
+        elif k == 7:                                 # an element becomes non-canonical / zero
+            i = 8 + eb * int(rng.integers(0, (n - 8) // eb - 1)); b[i:i + eb] = (b"\xff" if rng.integers(0, 2) else b"\x00") * eb
+        elif k == 8:                                 # splice: head of this file, tail of the file of another size
+            i = int(rng.integers(0, n)); b = b[:i] + bytearray(other[min(i, len(other) - 1):])
+        else:                                        # the trailing has_subtree bool / last bytes
+            b[-int(rng.integers(1, 10))] = int(rng.integers(0, 256))
+        return bytes(b)
+
+    codes = {}
+    accepted = 0
+    for case in range(2500):
+        bad = mutate(good)
+        h = ctypes.c_void_p()
+        rc = L.ecfft_fftree_deserialize(P.id, bad, len(bad), int(compress), 0, 1, ctypes.byref(h))
+        codes[rc] = codes.get(rc, 0) + 1
+        assert rc in (FT.OK, FT.ERR_BAD_ARG, FT.ERR_NOT_POW2, FT.ERR_TREE_TOO_LARGE), (case, rc)      # never ECFFT_ERR_HIP
+        assert (rc == FT.OK) == bool(h.value), case
+        if rc == FT.OK:
+            t = FT.FFTree(P, h, 0)
+            assert t.serialize(compress) == bad, f"case {case}: an accepted file is not what the loaded tree writes"
+            accepted += 1
+            del t
+    assert codes.get(FT.ERR_BAD_ARG, 0) > 2000, codes
+    # the unmutated file still loads afterwards (no state was corrupted on the way)
+    assert S.deserialize_fftree(P, good, compress, verify=True).n == 8
