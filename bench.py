@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="also report throughput with this many polynomials per launch (0 = skip)")
     ap.add_argument("--split-log-n", type=int, default=20, help="--gpus N > 1: size of the ONE ENTER+EXIT split over the ranks reported under `split` (0 = skip)")
     ap.add_argument("--split-log-e", type=int, default=22, help="--gpus N > 1: size of the ONE EXTEND split over the ranks reported under `split` (0 = skip)")
-    ap.add_argument("--stripe-min-gain", type=int, default=None, help="--gpus N > 1: ecfft_comm_set_link_striping threshold in bytes for the split part (default: the library's 4 MiB; 0 = always when it helps; -1 = never)")
+    ap.add_argument("--stripe-min-gain", type=int, default=None, help="--gpus N > 1: ecfft_comm_set_link_striping threshold in bytes for the split part (default: the library's — striping OFF since round 6; 4194304 = the projection's threshold; 0 = always when it helps; -1 = never)")
     ap.add_argument("--split-exit", default="auto", choices=["auto", "gather", "shard"],
                     help="--gpus N > 1: form of the split EXIT — gather: full (replicated) context, ONE all-gather, top levels redundant; shard: "
                          "EXIT-shard context, split top levels; auto: gather up to n = 2^21, shard above")

@@ -626,6 +626,53 @@ __device__ __forceinline__ void row_stages_pipe(typename F::elem* tile, const ty
     }
 }
 
+// Round 6, second form of the wave-local sweeps: the sweeps at pair distance 64 and 32 of a one-pair-per-thread
+// row tile with the PAIR KEPT IN REGISTERS between them.  After the sweep at distance 64 lane l of a wave holds elements (l, l + 64)
+// of the wave's 128-element span; the sweep at distance 32 wants (l, l + 32) in lanes < 32 and (l + 32, l + 64) in lanes >= 32: the
+// upper half-wave's low elements trade places with the lower half-wave's high elements — one v_permlane32_swap per register (8 per
+// pair); from distance 32 to 16 the same inside each half-wave: v_permlane16_swap.  No LDS write + read between the three sweeps.
+// ECFFT_ROW_REGS: 0 = through LDS (row_stages_pipe), 1 = registers.  A/B: profiles/r06/row_regs_ab.txt.
+#ifndef ECFFT_ROW_REGS
+#define ECFFT_ROW_REGS 0
+#endif
+template <class E>
+__device__ __forceinline__ void pair_swap32(E& a, E& b) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { auto p = __builtin_amdgcn_permlane32_swap(a.l[w], b.l[w], false, false); a.l[w] = p[0]; b.l[w] = p[1]; }
+}
+template <class E>
+__device__ __forceinline__ void pair_swap16(E& a, E& b) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { auto p = __builtin_amdgcn_permlane16_swap(a.l[w], b.l[w], false, false); a.l[w] = p[0]; b.l[w] = p[1]; }
+}
+// decompose at distance 64, then 32: reads the pair (idx6, idx6 + 64) from the tile (published by a barrier), returns the pair
+// (idx4, idx4 + 16), idx4 = ((tid >> 4) << 5) + (tid & 15), of the state after the distance-32 sweep — what the fused distance-16 sweep reads
+template <class F>
+__device__ __forceinline__ void row_regs_dec(const typename F::elem* tile, const typename F::telem* __restrict__ np0, const typename F::telem* __restrict__ dinv,
+                                             uint32_t e, uint32_t tid, typename F::elem& a, typename F::elem& b) {
+    const uint32_t l = tid & 63u, idx6 = ((tid >> 6) << 7) + l;
+    typename F::telem t0 = ldt(np0, e - 128u + l), t1 = ldt(dinv, e - 128u + l);
+    a = tile[idx6]; b = tile[idx6 + 64];
+    bfly<F, true>(a, b, t0, t1);
+    t0 = ldt(np0, e - 64u + (l & 31u)); t1 = ldt(dinv, e - 64u + (l & 31u));
+    pair_swap32(a, b);
+    bfly<F, true>(a, b, t0, t1);
+    pair_swap16(a, b);
+}
+// recombine at distance 32, then 64, from the pair (idx4, idx4 + 16) after the distance-16 sweep; writes the pair (idx6, idx6 + 64) to the tile
+template <class F>
+__device__ __forceinline__ void row_regs_rec(typename F::elem* tile, const typename F::telem* __restrict__ p0, const typename F::telem* __restrict__ p1,
+                                             uint32_t e, uint32_t tid, typename F::elem a, typename F::elem b) {
+    const uint32_t l = tid & 63u, idx6 = ((tid >> 6) << 7) + l;
+    typename F::telem t0 = ldt(p0, e - 64u + (l & 31u)), t1 = ldt(p1, e - 64u + (l & 31u));
+    pair_swap16(a, b);
+    bfly<F, false>(a, b, t0, t1);
+    t0 = ldt(p0, e - 128u + l); t1 = ldt(p1, e - 128u + l);
+    pair_swap32(a, b);
+    bfly<F, false>(a, b, t0, t1);
+    tile[idx6] = a; tile[idx6 + 64] = b;
+}
+
 template <class F, int LOG_TILE_CT>      // LOG_TILE_CT > 0: tile size known at compile time (loops unroll); 0: runtime log_tile
 __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDesc<F> io,
                                                            const typename F::telem* __restrict__ np0,
@@ -684,8 +731,10 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
     const bool fuse16 = mfma && T == (uint32_t)Blk16::kSub && k_first < k_dec_end;
     bool pipe = false;                                                  // one pair per thread: constants one sweep ahead
     if constexpr (sizeof(E) == 32 && ECFFT_ROW_PIPE) pipe = npairs == (uint32_t)kBlockRow && (e >> 31) == 0;
+    // registers across the sweeps at distance 64 / 32 / 16 (ECFFT_ROW_REGS): the pipelined sweeps stop above distance 64
+    const bool regs = ECFFT_ROW_REGS && sizeof(E) == 32 && pipe && fuse16 && log_e - k_first >= 7;
     if (pipe) {
-        if constexpr (sizeof(E) == 32) row_stages_pipe<F, true>(tile, np0, dinv, (uint32_t)e, (int)(log_e - k_first) - 1, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), tid, fuse16 ? 4 : 99);
+        if constexpr (sizeof(E) == 32) row_stages_pipe<F, true>(tile, np0, dinv, (uint32_t)e, (int)(log_e - k_first) - 1, regs ? 7 : (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), tid, fuse16 && !regs ? 4 : 99);
     } else
     for (uint32_t k = k_first; k < k_dec_end - (fuse16 ? 1u : 0u); ++k) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;
@@ -697,7 +746,9 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
             Blk16::APre pre;
             if (fuse16) {                                                // one pair per thread: (idx, idx + 16)
                 const uint32_t i = tid & 15u, idx = ((tid >> 4) << 5) + i;
-                const E a = tile[idx], b = tile[idx + 16];
+                E a, b;
+                if constexpr (ECFFT_ROW_REGS && sizeof(E) == 32) { if (regs) row_regs_dec<F>(tile, np0, dinv, (uint32_t)e, tid, a, b); else { a = tile[idx]; b = tile[idx + 16]; } }
+                else { a = tile[idx]; b = tile[idx + 16]; }
                 const E q1 = F::tmul(ldt(dinv + (e - 32), i), F::sub(b, a));
                 const E q0 = F::tmul_add(ldt(np0 + (e - 32), i), q1, a);
                 __builtin_amdgcn_sched_barrier(0);
@@ -725,9 +776,20 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
                 const E o0 = F::tmul_add(ldt(p0 + (e - 32), i), b, a), o1 = F::tmul_add(ldt(p1 + (e - 32), i), b, a);
                 // the swizzled positions read above and the plain ones written below lie in the wave's own span; so do the pairs of the
                 // recombine sweep at distance 32 that follows in the pipelined form
+                bool done_regs = false;
+                if constexpr (ECFFT_ROW_REGS && sizeof(E) == 32) {
+                    if (regs) {      // distance 32 and 64 in registers; the swizzled positions read above lie in the wave's own span, like the ones written
+                        if (ECFFT_WAVE_LOCAL) wave_local_sync(); else __syncthreads();
+                        row_regs_rec<F>(tile, p0, p1, (uint32_t)e, tid, o0, o1);
+                        lds_barrier();
+                        done_regs = true;
+                    }
+                }
+                if (!done_regs) {
                 if (ECFFT_WAVE_LOCAL) wave_local_sync(); else __syncthreads();
                 tile[idx] = o0; tile[idx + 16] = o1;
                 if (ECFFT_WAVE_LOCAL && pipe && k_first + 1 < k_dec_end) wave_local_sync(); else __syncthreads();
+                }
             } else {
                 Blk16::from_swizzled<kBlockRow>(tile, T, tid);
             }
@@ -754,7 +816,7 @@ __global__ __launch_bounds__(kBlockRow, ECFFT_MIN_WAVES) void k_stages_lds(IoDes
         __syncthreads();
     }
     if (pipe) {
-        if constexpr (sizeof(E) == 32) row_stages_pipe<F, false>(tile, p0, p1, (uint32_t)e, (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), (int)(log_e - k_first) - 1, tid);
+        if constexpr (sizeof(E) == 32) row_stages_pipe<F, false>(tile, p0, p1, (uint32_t)e, regs ? 7 : (int)(log_e - (k_dec_end - (fuse16 ? 1u : 0u))), (int)(log_e - k_first) - 1, tid);
     } else
     for (uint32_t k = k_dec_end - (fuse16 ? 1u : 0u); k-- > k_first;) {
         const uint32_t lh = log_e - k - 1, h = 1u << lh;

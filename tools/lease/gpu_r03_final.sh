@@ -19,6 +19,6 @@ g++ -O2 -std=c++17 -Iinclude examples/bench_fftree.cpp -Lecfft_amd -lecfft_hip -
 python tools/build_only.py > $O/build_times.txt 2>&1
 (cd tools/ubench && CLOCK_R3_ONLY=1 ./clock) > $O/clock_ubench_r3.txt 2>&1
 (cd tools/ubench && ./mfma_mul 2048 50 && ./mfma_mul_xstamps 512 10 | grep -A9 "grid 1)") > $O/ubench_mfma_mul.txt 2>&1
-python tools/big_sizes_check.py > $O/big_sizes.txt 2>&1
+python tools/big_sizes_check.py secp256k1:22 m31:25 > $O/big_sizes.txt 2>&1
 python tools/shard_emulate.py secp256k1 22 8 > $O/shard_emulate.txt 2>&1
 ls -la $O; python tools/bench_classes.py < $O/bench_default.json; python tools/bench_classes.py < $O/bench_m31_2e24.json

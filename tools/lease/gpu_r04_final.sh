@@ -21,7 +21,7 @@ ECFFT_NO_MFMA=1 ECFFT_NO_ROW256=1 ECFFT_NO_COL256=1 ECFFT_SMALL_MIN_LOGC=2 pytho
 g++ -O2 -std=c++17 -Iinclude examples/bench_fftree.cpp -Lecfft_amd -lecfft_hip -Wl,-rpath,$PWD/ecfft_amd -Wl,--allow-shlib-undefined -o /tmp/bench_fftree && /tmp/bench_fftree > $O/bench_fftree.txt 2>&1
 python tools/cold_build.py > $O/build_times.txt 2>&1
 (cd tools/ubench && ./mfma_mul16_da2 1024 50 && ./mfma_mul16_stamps 256 10 | grep -A5 "^stamps") > $O/ubench_mfma_mul16.txt 2>&1
-python tools/big_sizes_check.py > $O/big_sizes.txt 2>&1
+python tools/big_sizes_check.py secp256k1:22 m31:25 > $O/big_sizes.txt 2>&1
 python tools/shard_emulate.py secp256k1 22 8 > $O/shard_emulate.txt 2>&1
 python tools/split_project.py 20 25 48 2>&1 | grep -v amdgpu.ids > $O/split_projection.txt
 bash tools/trace_case.sh r04f_16 secp256k1 16 both 3 > /dev/null 2>&1; cp gpurun_out/trace_r04f_16/dispatches.txt $O/dispatches_secp_2e16.txt
