@@ -6,7 +6,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_DIR, "csrc", "ecfft_capi.hip")
 LIB = os.path.join(_DIR, "libecfft_hip.so")
 DEPS = [os.path.join(_DIR, "csrc", f) for f in
-        ("ecfft_capi.hip", "device_tree.h", "kernels.h", "host_curve.h", "field_secp256k1.h", "field_m31.h", "secp256k1_mul_gfx950.inc", "transport.h", "mfma_blk16.h")]
+        ("ecfft_capi.hip", "device_tree.h", "kernels.h", "host_curve.h", "field_secp256k1.h", "field_m31.h", "secp256k1_mul_gfx950.inc", "transport.h", "mfma_blk16.h", "wire_parse.h")]
 DEPS.append(os.path.join(os.path.dirname(_DIR), "include", "ecfft_hip.h"))
 DEPS.append(os.path.join(os.path.dirname(_DIR), "include", "ecfft_hip_hooks.h"))
 

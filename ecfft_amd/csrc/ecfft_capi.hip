@@ -4,6 +4,7 @@
 #include <memory>
 #include <new>
 #include "device_tree.h"
+#include "wire_parse.h"
 #include "../../include/ecfft_hip.h"
 #ifdef ECFFT_TEST_HOOKS
 #include "../../include/ecfft_hip_hooks.h"    // test / measurement entry points: never in the shipped library
@@ -546,93 +547,24 @@ int wire_write(DeviceChain<F>& ch, int compress, uint8_t* buf) {
     return ECFFT_OK;
 }
 
-// cursor over the file: every read is bounds-checked (a truncated or corrupt file is ECFFT_ERR_BAD_ARG, never a wild read)
-struct WireIn {
-    const uint8_t* p; size_t left; bool bad = false;
-    bool u64(uint64_t* v) {
-        if (left < 8) { bad = true; return false; }
-        uint64_t r = 0; for (int i = 0; i < 8; ++i) r |= (uint64_t)p[i] << (8 * i);
-        p += 8; left -= 8; *v = r; return true;
-    }
-    const uint8_t* bytes(size_t n) {
-        if (left < n) { bad = true; return nullptr; }
-        const uint8_t* r = p; p += n; left -= n; return r;
-    }
-};
-template <class F>
-bool canonical_elems(const uint8_t* p, size_t cnt) {          // every element < p (ark-serialize rejects non-canonical encodings)
-    for (size_t i = 0; i < cnt; ++i) {
-        if constexpr (std::is_same<F, Secp256k1>::value) {
-            Fe256 v; memcpy(&v, p + 32 * i, 32);
-            bool lt = false;
-            for (int w = 7; w >= 0; --w) { const uint32_t pl = Secp256k1::p_limb(w); if (v.l[w] != pl) { lt = v.l[w] < pl; break; } }
-            if (!lt) return false;
-        } else {
-            uint32_t v; memcpy(&v, p + 4 * i, 4);
-            if (v >= 0x7FFFFFFFu) return false;
-        }
-    }
-    return true;
-}
-// one level of a parsed file: pointers into the file for every table (standard form), in ECFFT_TBL_* order
-struct WireLevel { size_t n = 0; const uint8_t* tbl[11] = {}; size_t cnt[11] = {}; };
-
+// (the bounds-checked parse itself — cursor, canonicality check, level structure — lives in wire_parse.h: pure host C++ that
+// tests/cpp/wire_fuzz.cpp also drives under AddressSanitizer + UBSan without a GPU)
 template <class F>
 int wire_read(int field, const uint8_t* data, size_t len, int compress, int device, int verify, ecfft_ctx** out,
               std::unique_ptr<DeviceChain<F>> ecfft_ctx::*slot) {
     using E = typename F::elem;
     const size_t eb = sizeof(E);
-    WireIn in{data, len};
-    std::vector<WireLevel> levels;
+    static_assert(sizeof(E) == 32 || sizeof(E) == 4, "element sizes of the two fields");
+    wire::File file;
+    { const int prc = wire::parse(field, data, len, compress, file); if (prc != ECFFT_OK) return prc; }
+    const std::vector<wire::Level>& levels = file.levels;
+    typedef wire::Level WireLevel;
     HostTree<F> ht;
-    for (size_t expect = 0;; expect >>= 1) {
-        WireLevel lv;
-        auto vec = [&](int which, size_t per_entry, size_t want_entries, bool check_len) -> bool {
-            uint64_t n_ent = 0;
-            if (!in.u64(&n_ent)) return false;
-            if (check_len && n_ent != want_entries) { in.bad = true; return false; }
-            if (n_ent > in.left / (per_entry * eb)) { in.bad = true; return false; }
-            const uint8_t* q = in.bytes((size_t)n_ent * per_entry * eb);
-            if (!q || !canonical_elems<F>(q, (size_t)n_ent * per_entry)) { in.bad = true; return false; }
-            lv.tbl[which] = q; lv.cnt[which] = (size_t)n_ent * per_entry;
-            return true;
-        };
-        if (!vec(ECFFT_TBL_F, 1, 0, false)) return ECFFT_ERR_BAD_ARG;
-        const size_t two_m = lv.cnt[ECFFT_TBL_F];
-        if (two_m < 2 || (two_m & (two_m - 1))) return two_m >= 2 ? ECFFT_ERR_NOT_POW2 : ECFFT_ERR_BAD_ARG;
-        const size_t m = two_m / 2;
-        if (levels.empty()) expect = m; else if (m != expect) return ECFFT_ERR_BAD_ARG;
-        lv.n = m;
-        const unsigned lm = ilog2(m);
-        if (!vec(ECFFT_TBL_RECOMBINE, 4, m, true) || !vec(ECFFT_TBL_DECOMPOSE, 4, m, true)) return ECFFT_ERR_BAD_ARG;
-        uint64_t nmaps = 0;
-        if (!in.u64(&nmaps) || nmaps != lm) return ECFFT_ERR_BAD_ARG;
-        for (unsigned k = 0; k < lm; ++k) {
-            RatMap<F> mp;
-            for (int side = 0; side < 2; ++side) {
-                uint64_t nc = 0;
-                if (!in.u64(&nc) || nc > 3) return ECFFT_ERR_BAD_ARG;
-                const uint8_t* q = in.bytes((size_t)nc * eb);
-                if (!q || !canonical_elems<F>(q, (size_t)nc)) return ECFFT_ERR_BAD_ARG;
-                E* dst = side ? mp.den : mp.num;
-                for (int i = 0; i < 3; ++i) dst[i] = F::zero();
-                memcpy(dst, q, (size_t)nc * eb);
-            }
-            if (!F::is_zero(mp.den[2])) return ECFFT_ERR_BAD_ARG;          // x-map denominators have degree 1
-            if (levels.empty()) ht.maps.push_back(mp);
-            else if (memcmp(&ht.maps[k], &mp, sizeof(mp)) != 0) return ECFFT_ERR_BAD_ARG;   // a subtree keeps its parent's first maps
-        }
-        const size_t e = m / 2, zz = m > 1 ? m : 0;
-        if (!vec(ECFFT_TBL_XNN_S, 1, m, true) || !vec(ECFFT_TBL_Z0_S1, 1, e, true) || !vec(ECFFT_TBL_Z1_S0, 1, e, true)) return ECFFT_ERR_BAD_ARG;
-        if (!compress && (!vec(ECFFT_TBL_XNN_S_INV, 1, m, true) || !vec(ECFFT_TBL_Z0_INV_S1, 1, e, true) || !vec(ECFFT_TBL_Z1_INV_S0, 1, e, true))) return ECFFT_ERR_BAD_ARG;
-        if (!vec(ECFFT_TBL_Z0Z0_REM_XNN_S, 1, zz, true) || !vec(ECFFT_TBL_Z1Z1_REM_XNN_S, 1, zz, true)) return ECFFT_ERR_BAD_ARG;
-        const uint8_t* hs = in.bytes(1);
-        if (!hs || *hs > 1) return ECFFT_ERR_BAD_ARG;
-        levels.push_back(lv);
-        if (!*hs) { if (m != 1) return ECFFT_ERR_BAD_ARG; break; }
-        if (m == 1) return ECFFT_ERR_BAD_ARG;
+    for (const wire::Map& m : file.maps) {
+        RatMap<F> mp;
+        for (int i = 0; i < 3; ++i) { memcpy(&mp.num[i], m.num[i], eb); memcpy(&mp.den[i], m.den[i], eb); }
+        ht.maps.push_back(mp);
     }
-    if (in.left != 0) return ECFFT_ERR_BAD_ARG;                            // trailing bytes
     // FFTree::new on the file's leaves and maps: every other table is recomputed on the GPU (the reference USES the file's
     // tables; with verify != 0 each of them is compared with the recomputed one, so a file whose tables disagree with its own
     // point set is rejected instead of being silently repaired).  Compress::Yes files carry no inverse tables (:620-628).
