@@ -939,6 +939,21 @@ public:
         return hipGetLastError() == hipSuccess;
     }
 
+    // ecfft_extend with count > 1 (the low-degree extension of many columns): like a batched ENTER / EXIT, an even batch of at least
+    // 2^(kSplitMinLog + 1) elements runs as two half-batches of whole vectors on two streams (round 6, batch_split)
+    bool extend_api(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) {
+        const size_t total = e * count;
+        if (!batch_split(total, count)) return extend(in, out, e, count, target, s);
+        hipStream_t s2 = sides_[0];
+        (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
+        in_halves_ = true;
+        bool ok = extend(in, out, e, count / 2, target, s);
+        double w = tblw_; tblw_ = 0.0; ok = extend(in + total / 2, out + total / 2, e, count / 2, target, s2) && ok; tblw_ = w;
+        in_halves_ = false;
+        (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
+        return ok;
+    }
+
     // ------------------------------------------------------------------------------------------
     // Building blocks of ONE EXTEND split over P = 2^log_p GPUs.  The vector of
     // length e lives on T_{2e}; `target` is the target moiety.

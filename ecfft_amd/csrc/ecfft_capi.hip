@@ -131,7 +131,7 @@ int run_op(ecfft_ctx* c, DeviceChain<F>& ch, Op op, const void* in, void* out, s
     switch (op) {
         case OP_ENTER: ok = ch.enter(din, dout, len, count, s); break;
         case OP_EXIT: ok = ch.exit(din, dout, len, count, s); break;
-        case OP_EXTEND: ok = ch.extend(din, dout, len, count, moiety, s); break;
+        case OP_EXTEND: ok = ch.extend_api(din, dout, len, count, moiety, s); break;
     }
     if (!ok || hipGetLastError() != hipSuccess) return ECFFT_ERR_HIP;
     if (mem == ECFFT_MEM_HOST) {
