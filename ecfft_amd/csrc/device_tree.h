@@ -943,7 +943,9 @@ public:
     // 2^(kSplitMinLog + 1) elements runs as two half-batches of whole vectors on two streams (round 6, batch_split)
     bool extend_api(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) {
         const size_t total = e * count;
-        if (!batch_split(total, count)) return extend(in, out, e, count, target, s);
+        // only for LONG vectors (e >= 2^kSplitMinLog): their launches are one or two rounds of tiles, which is what a second stream fills
+        // (-2.5 .. -4.4 % at e = 2^19 .. 2^22); many short vectors are deep launches already (2^16 x 32: +1.3 %, profiles/r06/extend_split_ab.txt)
+        if (!batch_split(total, count) || (e >> kSplitMinLog) == 0) return extend(in, out, e, count, target, s);
         hipStream_t s2 = sides_[0];
         (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
         in_halves_ = true;

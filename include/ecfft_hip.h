@@ -97,7 +97,8 @@ int ecfft_exit(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, int me
 int ecfft_enter_many(ecfft_ctx* ctx, const void* coeffs, void* evals, size_t n, size_t count, int mem, void* stream);
 int ecfft_exit_many(ecfft_ctx* ctx, const void* evals, void* coeffs, size_t n, size_t count, int mem, void* stream);
 /* `count` vectors of `e` evaluations on the moiety opposite to `moiety` -> evaluations on `moiety`
- * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend). */
+ * of T_{2e}; vectors are laid end to end (count = 1 is FFTree::extend).  (An even batch of >= 2^20 elements of vectors with
+ * e >= 2^19 runs as two half-batches on two streams, like the batched ENTER / EXIT.) */
 int ecfft_extend(ecfft_ctx* ctx, const void* in, void* out, size_t e, int moiety, size_t count, int mem, void* stream);
 
 /* The remaining FFTree algorithms, composed from the same GPU kernels.  Synchronous.

@@ -22,7 +22,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ecfft_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".inc")) and f not in ("host_curve.h", "transport.h"):      # device code + launch logic
+        if f.endswith((".h", ".inc")) and f not in ("host_curve.h", "transport.h", "wire_parse.h"):      # device code + launch logic (not the host-only headers)
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode()); h.update(fh.read())
     return h.hexdigest()[:16]
