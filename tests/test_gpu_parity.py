@@ -42,14 +42,25 @@ class _OracleHeadline:
         return rand_elems(self.F, n, 0x5EED0500 + log_n), rand_elems(self.F, n, 0x5EED0600 + log_n)
 
     def _size(self, ot, log_n):
-        try:
-            c, r = self.inputs(log_n)
-            h = r[: (1 << log_n) // 2]
-            self.res[log_n] = dict(enter=ot.enter(c), exit=ot.exit(r), ext_s1=ot.extend(h, self.o.S1), ext_s0=ot.extend(h, self.o.S0))
-            if log_n in self.second:          # round 6: a second polynomial per size, for the batched calls (ecfft_enter_many / _exit_many)
-                self.res[log_n]["enter2"] = ot.enter(r)
-        except Exception as e:  # pragma: no cover
-            self.err.append(e)
+        """the transforms of one size, each on its own host thread (read-only on the tree; the oracle keeps per-thread vector caches): the
+        critical path of the session is the longest single transform after the tree build (EXIT of 2^20: ~45 s), not their sum"""
+        import threading
+        c, r = self.inputs(log_n)
+        h = r[: (1 << log_n) // 2]
+        res = {}
+        jobs = {"enter": lambda: ot.enter(c), "exit": lambda: ot.exit(r), "ext_s1": lambda: ot.extend(h, self.o.S1), "ext_s0": lambda: ot.extend(h, self.o.S0)}
+        if log_n in self.second:          # round 6: a second polynomial per size, for the batched calls (ecfft_enter_many / _exit_many)
+            jobs["enter2"] = lambda: ot.enter(r)
+
+        def run(name, fn):
+            try:
+                res[name] = fn()
+            except Exception as e:  # pragma: no cover
+                self.err.append(e)
+        th = [threading.Thread(target=run, args=kv) for kv in jobs.items()]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        self.res[log_n] = res
 
     def _run(self):
         import threading
