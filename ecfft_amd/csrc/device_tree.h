@@ -106,6 +106,12 @@ private:
          hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);               \
          if (prof_.on) prof_.end(stream); } while (0)
 
+#ifndef ECFFT_BATCH_SPLIT
+#define ECFFT_BATCH_SPLIT 1
+#endif
+#ifndef ECFFT_BATCH_WAYS
+#define ECFFT_BATCH_WAYS 2      // a batch runs as up to this many concurrent parts (whole polynomials each, one stream per part); A/B: profiles/r06/batch_ways_ab.txt
+#endif
 template <class F>
 class DeviceChain {
 public:
@@ -206,7 +212,8 @@ public:
     unsigned shard_rank() const { return shard_rank_; }
     // side streams of the two-halves schedule (enter_rec / exit_rec)
     void create_side_streams() {
-        for (nside_ = 0; nside_ < (1 << kSplitDepth) - 1 && nside_ < kMaxSides; ++nside_) {
+        const int want = ((1 << kSplitDepth) - 1) > (ECFFT_BATCH_WAYS - 1) ? ((1 << kSplitDepth) - 1) : (ECFFT_BATCH_WAYS - 1);   // halves of one transform / parts of a batch
+        for (nside_ = 0; nside_ < want && nside_ < kMaxSides; ++nside_) {
             if (hipStreamCreateWithFlags(&sides_[nside_], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork_[nside_], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_join_[nside_], hipEventDisableTiming) != hipSuccess) break;
         }
@@ -939,20 +946,17 @@ public:
         return hipGetLastError() == hipSuccess;
     }
 
-    // ecfft_extend with count > 1 (the low-degree extension of many columns): like a batched ENTER / EXIT, an even batch of at least
-    // 2^(kSplitMinLog + 1) elements runs as two half-batches of whole vectors on two streams (round 6, batch_split)
+    // ecfft_extend with count > 1 (the low-degree extension of many columns): like a batched ENTER / EXIT, a batch whose parts have at
+    // least 2^kSplitMinLog elements runs as concurrent parts of whole vectors, one stream each (round 6, batch_ways / run_ways)
     bool extend_api(const E* in, E* out, size_t e, size_t count, int target, hipStream_t s) {
         const size_t total = e * count;
         // only for LONG vectors (e >= 2^kSplitMinLog): their launches are one or two rounds of tiles, which is what a second stream fills
         // (-2.5 .. -4.4 % at e = 2^19 .. 2^22); many short vectors are deep launches already (2^16 x 32: +1.3 %, profiles/r06/extend_split_ab.txt)
-        if (!batch_split(total, count) || (e >> kSplitMinLog) == 0) return extend(in, out, e, count, target, s);
-        hipStream_t s2 = sides_[0];
-        (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
-        in_halves_ = true;
-        bool ok = extend(in, out, e, count / 2, target, s);
-        double w = tblw_; tblw_ = 0.0; ok = extend(in + total / 2, out + total / 2, e, count / 2, target, s2) && ok; tblw_ = w;
-        in_halves_ = false;
-        (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
+        const int ways = (e >> kSplitMinLog) == 0 ? 1 : batch_ways(total, count);
+        if (ways <= 1) return extend(in, out, e, count, target, s);
+        const size_t part = total / (size_t)ways, cnt = count / (size_t)ways;
+        bool ok = true;
+        run_ways(ways, s, [&](int i, hipStream_t si) { ok = extend(in + part * i, out + part * i, e, cnt, target, si) && ok; });
         return ok;
     }
 
@@ -1397,26 +1401,35 @@ public:
             in_halves_ = true;
             enter_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
             in_halves_ = false;
-        } else if (batch_split(nt, count)) {
-            // round 6: a batch runs as two half-batches on two streams (whole polynomials: nothing to join but the end) — one half's
-            // load / store phases and launch fill / drain meet the other's multiplies, as in the two-halves schedule of one transform
-            hipStream_t s2 = sides_[0];
-            (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
-            in_halves_ = true;
-            enter_levels(in, out, n, count / 2, s, scratch_, 1, ln);
-            double w = tblw_; tblw_ = 0.0; enter_levels(in + nt / 2, out + nt / 2, n, count / 2, s2, scratch_ + 3 * (nt / 2), 1, ln); tblw_ = w;
-            in_halves_ = false;
-            (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
+        } else if (const int ways = batch_ways(nt, count); ways > 1) {
+            // round 6: a batch runs as `ways` parts of whole polynomials on as many streams — nothing to join but the end: one part's
+            // load / store phases and launch fill / drain meet the others' multiplies, as in the two-halves schedule of one transform
+            const size_t part = nt / (size_t)ways, cnt = count / (size_t)ways;
+            run_ways(ways, s, [&](int i, hipStream_t si) { enter_levels(in + part * i, out + part * i, n, cnt, si, scratch_ + 3 * part * i, 1, ln); });
         } else {
             enter_levels(in, out, n, count, s, scratch_, 1, ln);
         }
         return true;
     }
-#ifndef ECFFT_BATCH_SPLIT
-#define ECFFT_BATCH_SPLIT 1
-#endif
-    // batched ENTER / EXIT as two concurrent half-batches: an even number of polynomials, each half at least 2^kSplitMinLog elements
-    bool batch_split(size_t nt, size_t count) const { return ECFFT_BATCH_SPLIT && count > 1 && (count & 1) == 0 && nside_ > 0 && (nt >> (kSplitMinLog + 1)) != 0; }
+    // fork `ways - 1` side streams off `s`, run part i on stream i (part 0 on `s` itself), join them back into `s`
+    template <class Fn>
+    void run_ways(int ways, hipStream_t s, Fn fn) {
+        for (int i = 1; i < ways; ++i) { (void)hipEventRecord(ev_fork_[i - 1], s); (void)hipStreamWaitEvent(sides_[i - 1], ev_fork_[i - 1], 0); }
+        in_halves_ = true;
+        const double w = tblw_;
+        for (int i = 0; i < ways; ++i) { if (i) tblw_ = 0.0; fn(i, i ? sides_[i - 1] : s); }     // (the tables are credited once in the byte model)
+        tblw_ = w;
+        in_halves_ = false;
+        for (int i = 1; i < ways; ++i) { (void)hipEventRecord(ev_join_[i - 1], sides_[i - 1]); (void)hipStreamWaitEvent(s, ev_join_[i - 1], 0); }
+    }
+    // batched ENTER / EXIT / EXTEND as concurrent parts: the number of parts (1 = one stream) — a power of two <= ECFFT_BATCH_WAYS that
+    // divides the count, every part at least 2^kSplitMinLog elements
+    int batch_ways(size_t nt, size_t count) const {
+        if (!ECFFT_BATCH_SPLIT || count < 2) return 1;
+        for (int w = ECFFT_BATCH_WAYS; w >= 2; w >>= 1)
+            if (count % (size_t)w == 0 && w - 1 <= nside_ && ((nt / (size_t)w) >> kSplitMinLog) != 0) return w;
+        return 1;
+    }
     // Concurrent halves, recursively: levels 1..L-1 never mix the two half-blocks, so they run as two independent ENTERs
     // of n/2 on two streams.  Their launches (each half as wide) interleave on the chip, so one half's load / store phases
     // overlap the other's compute; only the top level runs on the whole array.  Scratch: f(n) = n + 2 f(n/2), f = 3n at a leaf.
@@ -1513,14 +1526,9 @@ public:
             in_halves_ = true;
             exit_rec(in, out, n, s, scratch_, kSplitDepth, next_side);
             in_halves_ = false;
-        } else if (batch_split(n, count)) {
-            hipStream_t s2 = sides_[0];
-            (void)hipEventRecord(ev_fork_[0], s); (void)hipStreamWaitEvent(s2, ev_fork_[0], 0);
-            in_halves_ = true;
-            exit_levels(in, out, n1, count / 2, s, scratch_, ln, 1);
-            double w = tblw_; tblw_ = 0.0; exit_levels(in + n / 2, out + n / 2, n1, count / 2, s2, scratch_ + 3 * (n / 2), ln, 1); tblw_ = w;
-            in_halves_ = false;
-            (void)hipEventRecord(ev_join_[0], s2); (void)hipStreamWaitEvent(s, ev_join_[0], 0);
+        } else if (const int ways = batch_ways(n, count); ways > 1) {
+            const size_t part = n / (size_t)ways, cnt = count / (size_t)ways;
+            run_ways(ways, s, [&](int i, hipStream_t si) { exit_levels(in + part * i, out + part * i, n1, cnt, si, scratch_ + 3 * part * i, ln, 1); });
         } else {
             exit_levels(in, out, n1, count, s, scratch_, ln, 1);
         }
