@@ -805,6 +805,8 @@ public:
         int nd = np;
         passes[np++] = {1, k_first, le};
         for (int g = nd - 1; g >= 0; --g) passes[np++] = {2, passes[g].ka, passes[g].kb};
+        // results of launches of at most 2^kNtStoreMaxLog elements leave with non-temporal stores (kernels.h data_st; 32-byte fields)
+        const uint32_t nt_st = (sizeof(E) == 32 && kNtStoreMaxLog && total <= ((size_t)1 << kNtStoreMaxLog)) ? 1u : 0u;
         const E* plain_src = buf;
         const bool fuse_tail = next_ld && nd >= 1 && (io.st_mode == ST_PLAIN || io.st_mode == ST_SCALE || io.st_mode == ST_AXPBY) && io.dst == buf;
         const int pi0 = (skip_first_col && nd >= 1) ? 1 : 0;
@@ -814,7 +816,7 @@ public:
             if (last && fuse_tail) {
                 // this core's last recombine group + the next core's first decompose group (same stages, same tiles)
                 const Pass& P = passes[pi];
-                d = io; d.src = buf; d.dst = buf; d.ld_mode = next_ld->ld_mode; d.ld_tbl = next_ld->ld_tbl;
+                d = io; d.src = buf; d.dst = buf; d.ld_mode = next_ld->ld_mode; d.ld_tbl = next_ld->ld_tbl; d.nt_st = nt_st;
                 unsigned log_ct = tz < kLogColTileMax ? tz : kLogColTileMax;
                 if (small && log_ct > kLogLowSmall) log_ct = kLogLowSmall;
                 unsigned R = P.kb - P.ka + 1, log_c = log_ct - R;
@@ -851,6 +853,7 @@ public:
             if (last) { d.dst = io.dst; d.st_mode = io.st_mode; d.st_a = io.st_a; d.st_b = io.st_b; d.aux = io.aux; d.aux_stride = io.aux_stride; d.aux_off = io.aux_off; d.aux_out = io.aux_out;
                         d.st_tr_logp = io.st_tr_logp; d.tr_chunk = io.tr_chunk; }
             else { d.dst = buf; d.st_mode = ST_PLAIN; d.st_a = d.st_b = nullptr; d.aux = nullptr; d.aux_stride = d.aux_off = 0; d.aux_out = nullptr; }
+            d.nt_st = nt_st;
             double extra = (first ? extra_first : 0.0) + (last ? extra_last : 0.0);
             const Pass& P = passes[pi];
             if (last && ef) {   // row pass is the last one: pair store operator
@@ -1495,6 +1498,12 @@ public:
 #ifndef ECFFT_SPLIT_DEPTH
 #define ECFFT_SPLIT_DEPTH 1
 #endif
+#ifndef ECFFT_NT_STORE_MAX_LOG
+#define ECFFT_NT_STORE_MAX_LOG 0
+#endif
+    // launches of <= 2^this elements store their results non-temporally (IoDesc::nt_st, kernels.h data_st); 0 = never, the shipped value:
+    // the non-temporal store itself measures neutral (<= 2^19) to negative (above) — profiles/r06/nt_data_ab.txt
+    static constexpr unsigned kNtStoreMaxLog = ECFFT_NT_STORE_MAX_LOG;
     static constexpr unsigned kSplitDepth = ECFFT_SPLIT_DEPTH;      // recursion depth of the halving (2^depth concurrent streams)
     static constexpr int kMaxSides = 7;
     static constexpr unsigned kLogLow = (sizeof(E) == 32) ? 10 : 13;     // tile of the fused low-level kernels (2 x 32 KiB of LDS)

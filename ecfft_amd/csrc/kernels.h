@@ -116,8 +116,30 @@ struct IoDesc {
     //                  pos + e, both still in the tile; aux = the level's input blocks [u0 | v0])
     //                  dst[b*2e + 2i] = aux[b*2e + i] + st_a[i]*aux[b*2e + e + i];  dst[b*2e + 2i + 1] = st_c[i]*x + st_b[i]*y
     E* dst; int st_mode; const TE* st_a; const TE* st_b; const E* aux; uint32_t aux_stride, aux_off; E* aux_out; const TE* st_c;
+    uint32_t nt_st;      // != 0: non-temporal stores of the pass's results (data_st; launches of the latency regime)
 };
 
+// Result stores of the fused passes (32-byte fields) go through data_st: two explicit 16-byte vector stores, non-temporal when the host
+// sets IoDesc::nt_st for the launch (DeviceChain::kNtStoreMaxLog; wave-uniform branch).  Round 6, measured on MI355X
+// (profiles/r06/nt_data_ab.txt): the NON-TEMPORAL store itself buys nothing — flag set for launches <= 2^17 .. 2^19: +-0.3 % against the flag
+// never set; set everywhere: +1.5 .. +3 % from 2^20 on (the next pass wants the results in cache); non-temporal LOADS of the tile data
+// lose everywhere — so the shipped library never sets the flag.  What DOES pay is this form of the store: with it hipcc allocates the
+// latency-regime column kernels differently (k_stages_col256 77 -> 101 VGPRs, k_stages_col_mid256 102 -> 94; same instructions, more loads
+// in flight) and single transforms of 2^12 .. 2^19 run 0.7 - 3.2 % faster than with a plain `dst[pos] = x` (2^16 -0.7 %, 2^17 -1.5 %,
+// 2^18 -1.4 %, 2^19 -3.2 %; >= 2^20 and batches unchanged), interleaved on one box against the previous sources.
+typedef uint32_t nt_v4u __attribute__((ext_vector_type(4)));
+template <class E>
+__device__ __forceinline__ void data_st(E* p, const E& x, uint32_t nt) {
+    if constexpr (sizeof(E) == 32) {
+        if (nt) {                                                        // wave-uniform
+            nt_v4u* q = reinterpret_cast<nt_v4u*>(p);
+            nt_v4u a = {x.l[0], x.l[1], x.l[2], x.l[3]}, b = {x.l[4], x.l[5], x.l[6], x.l[7]};
+            __builtin_nontemporal_store(a, q); __builtin_nontemporal_store(b, q + 1);
+            return;
+        }
+    }
+    *p = x;
+}
 template <class F>
 __device__ __forceinline__ typename F::elem io_load(const IoDesc<F>& io, size_t pos, size_t emask) {
     typename F::elem v = io.ld_tr_logp ? io.src[(pos & (((size_t)1 << io.ld_tr_logp) - 1)) * io.tr_chunk + (pos >> io.ld_tr_logp)]
@@ -132,12 +154,12 @@ __device__ __forceinline__ void io_store(const IoDesc<F>& io, size_t pos, uint32
     switch (io.st_mode) {
         case ST_PLAIN:   // st_tr_logp > 0: the mirror image of the transposed load — scatter into the send chunks of an all-to-all
             if (io.st_tr_logp) io.dst[(pos & (((size_t)1 << io.st_tr_logp) - 1)) * io.tr_chunk + (pos >> io.st_tr_logp)] = F::canon(x);
-            else io.dst[pos] = F::canon(x);
+            else data_st(&io.dst[pos], F::canon(x), io.nt_st);
             break;
-        case ST_SCALE: io.dst[pos] = F::canon(F::tmul(io.st_a[i], x)); break;
+        case ST_SCALE: data_st(&io.dst[pos], F::canon(F::tmul(io.st_a[i], x)), io.nt_st); break;
         case ST_AXPBY: {
             E r = F::canon(F::tmul_add(io.st_a[i], x, F::tmul(io.st_b[i], io.aux[(size_t)io.aux_stride * pos + io.aux_off])));
-            io.dst[pos] = r;
+            data_st(&io.dst[pos], r, io.nt_st);
             if (io.aux_out) io.aux_out[pos] = r;
             break;
         }
@@ -145,8 +167,8 @@ __device__ __forceinline__ void io_store(const IoDesc<F>& io, size_t pos, uint32
             E u0 = F::canon(F::tmul(io.st_a[i], x));
             E v0 = F::canon(F::tmul(io.st_b[i], F::sub(io.aux[2 * pos], u0)));
             size_t base = (pos >> log_e) << (log_e + 1);
-            io.dst[base + i] = u0;
-            io.dst[base + ((size_t)1 << log_e) + i] = v0;
+            data_st(&io.dst[base + i], u0, io.nt_st);
+            data_st(&io.dst[base + ((size_t)1 << log_e) + i], v0, io.nt_st);
         }
     }
 }
@@ -1215,7 +1237,7 @@ __global__ __launch_bounds__(kBlockLds, ECFFT_MIN_WAVES) void k_stages_col_mid(I
 #ifndef ECFFT_EXP_NO_TILE_IO
     for (uint32_t j = tid; j < T; j += kBlockLds) {
         uint32_t r = j >> log_c, cc = j & (C - 1);
-        io.dst[B + ((size_t)r << log_hs) + cc] = F::canon(tile[r * col_row_stride<E>(C) + cc]);
+        data_st(&io.dst[B + ((size_t)r << log_hs) + cc], F::canon(tile[r * col_row_stride<E>(C) + cc]), io.nt_st);
     }
 #endif
 }
@@ -1458,7 +1480,7 @@ __global__ __launch_bounds__(256, 2) void k_stages_col_mid256(IoDesc<F> io, cons
         reg_col_stages<F, false>(x, xch, R, log_c, log_hs, c0, 1u << log_e, p0, p1, tid);
         x = io_mid<F>(io, pos, ((size_t)1 << log_e) - 1, x);
         reg_col_stages<F, true>(x, xch, R, log_c, log_hs, c0, 1u << log_e, c0t, dinv, tid);
-        io.dst[pos] = F::canon(x);
+        data_st(&io.dst[pos], F::canon(x), io.nt_st);
     }
 }
 // k_stages_col_enter for 256-element tiles: 512 threads, thread tid < 256 holds the U element, tid >= 256 the V element of the same
