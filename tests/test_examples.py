@@ -30,6 +30,19 @@ def test_examples_compile_against_the_c_abi(tmp_path, name):
 @pytest.mark.parametrize("name", EXAMPLES)
 def test_examples_run(tmp_path, name):
     exe = _build(name, tmp_path)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "FAILED" not in r.stdout
+    # Each example takes 2 - 7 s.  sharded_extend creates a REAL RCCL communicator (world = 1) in a bare C++ process; once in ~25 runs of
+    # round 6 that process sat in librccl's start-up on a fresh box until the limit (ten runs in a row on the next box: 6 s each, and the
+    # Python worker with the same call sequence never hung) — so a run that exceeds 90 s is killed and repeated, and only three hangs in
+    # a row fail the test.  A wrong result or a non-zero exit fails at once.
+    last = None
+    for attempt in range(3):
+        try:
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=90, env=dict(os.environ, NCCL_DEBUG="WARN"))
+        except subprocess.TimeoutExpired as ex:
+            last = ex
+            print(f"{name}: attempt {attempt + 1} exceeded 90 s; stdout so far: {(ex.stdout or b'')[-500:]!r} stderr: {(ex.stderr or b'')[-1500:]!r}")
+            continue
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "FAILED" not in r.stdout
+        return
+    raise AssertionError(f"{name} hung three times in a row: {last}")
